@@ -1,0 +1,126 @@
+/*
+ * yawhip.h -- C ABI of libyawhip.so: MI355X (gfx950) angular pair counting for yet_another_wizz.
+ *
+ * The reference (jlvdb/yet_another_wizz, pure Python) has no FFI of its own; the seam this library
+ * replaces is the per-job loop of
+ *     PatchLinkage.count_pairs                       src/yaw/correlation/measurements.py:344-364
+ * i.e. for every linked patch pair and every redshift bin one call of
+ *     process_patch_pair -> AngularTree.count        measurements.py:88-128, src/yaw/catalog/trees.py:303-362
+ *     -> scipy KDTree.count_neighbors                trees.py:348-353
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md (a ctypes stub).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is caller-owned host memory unless stated otherwise,
+ *     contiguous, 8-byte aligned; the library owns all device memory behind opaque handles;
+ *   - one context = one GPU = (normally) one process; calls are blocking and must not be issued
+ *     concurrently on the same context;
+ *   - every function returns 0 on success or a negative yawhip_status; nothing throws;
+ *     yawhip_last_error() returns a thread-local, human readable message for the last failure.
+ */
+#ifndef YAWHIP_H
+#define YAWHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YAWHIP_ABI_VERSION 1
+
+typedef enum yawhip_status {
+    YAWHIP_OK = 0,
+    YAWHIP_ERR_INVALID = -1,   /* bad argument (NULL handle, negative size, unsorted thresholds ...) */
+    YAWHIP_ERR_NO_DEVICE = -2, /* no usable HIP device / device id out of range */
+    YAWHIP_ERR_HIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
+    YAWHIP_ERR_OOM = -4,       /* device or host allocation failed */
+    YAWHIP_ERR_MISMATCH = -5   /* catalogs do not fit together (patch count, bin count, context) */
+} yawhip_status;
+
+/* Which device code path counts the pairs. All of them return identical results. */
+typedef enum yawhip_kernel {
+    YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path */
+    YAWHIP_KERNEL_EXACT = 1,  /* plain FP64 brute force over every candidate pair */
+    YAWHIP_KERNEL_FILTER = 2, /* FP32 guard-banded pre-filter, FP64 re-evaluation of survivors */
+    YAWHIP_KERNEL_SWEEP = 3   /* FILTER + sorted-axis sweep that skips far-away tile pairs */
+} yawhip_kernel;
+
+typedef struct yawhip_ctx yawhip_ctx;
+typedef struct yawhip_catalog yawhip_catalog;
+
+/* Filled by yawhip_count_pairs (may be NULL). Times are milliseconds. */
+typedef struct yawhip_stats {
+    int64_t candidate_pairs;   /* sum over (job, bin) of N1(p,k) * N2(q,k): the brute-force work unit   */
+    int64_t evaluated_pairs;   /* pair distances the launched kernels actually evaluated (<= candidates
+                                  when tile culling is active, padded lanes not included)               */
+    int64_t algorithmic_bytes; /* compulsory HBM bytes: every object of every (job,bin) segment once     */
+    int64_t n_workgroups;      /* workgroups of the dominant (count) kernel                              */
+    int32_t n_launches;        /* kernel launches in this call                                           */
+    int32_t kernel_used;       /* yawhip_kernel actually run                                             */
+    double kernel_ms;          /* HIP-event time of the count kernel(s) on the context's stream          */
+    double total_ms;           /* host wall time of the whole call (job upload, kernels, result download)*/
+} yawhip_stats;
+
+const char *yawhip_last_error(void);
+int yawhip_abi_version(void);
+
+/* Number of visible HIP devices. */
+int yawhip_device_count(int *n);
+
+/* Create / destroy a context on device `device_id` (creates one HIP stream). */
+int yawhip_ctx_create(int device_id, yawhip_ctx **out);
+int yawhip_ctx_destroy(yawhip_ctx *ctx);
+
+/* Tunables (all optional): "tile_r" objects per lane (1,2,4), "kernel" default yawhip_kernel. */
+int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
+
+/*
+ * Upload one catalogue (replaces: Catalog.build_trees + the per-job pickle.load of trees.pkl,
+ * catalog.py:1406-1461, trees.py:365-429,597).
+ *   n            objects kept (objects outside the redshift binning are already dropped, trees.py:414)
+ *   x,y,z        unit vectors, float64[n], exactly the host's AngularCoordinates.to_3d() values
+ *   w            float64[n] weights or NULL (unweighted)
+ *   n_patches    P
+ *   n_bins_or_1  B for a catalogue binned in redshift, 1 for an unbinned one (single tree re-used
+ *                for every bin, trees.py:600-601)
+ *   offsets      int64[P * n_bins_or_1 + 1], CSR over (patch, bin) segments; objects are sorted by
+ *                (patch, bin); offsets[0] == 0, offsets[last] == n, non-decreasing
+ * Order of objects inside a segment is free (it only permutes floating point summation order).
+ */
+int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+                          const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
+                          yawhip_catalog **out);
+int yawhip_catalog_free(yawhip_catalog *cat);
+/* Device bytes held by a catalogue (for memory accounting). */
+int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
+
+/*
+ * Count pairs for a list of jobs (replaces measurements.py:344-364 up to, not including, the
+ * scatter into [S,B,P,P] and the rweight / scale recombination of trees.py:358-362, which stay
+ * on the host because they are O(jobs * B * E)).
+ *   c1, c2     catalogues on the same context with equal n_patches; c1 == c2 is allowed (DD / RR
+ *              of an autocorrelation): every ordered pair a != b is then counted, self pairs have
+ *              s == 0 and never fall above an edge, exactly as in the reference
+ *   jobs       int32[n_jobs][2] = (patch id in c1, patch id in c2)
+ *   n_bins     B; a catalogue uploaded with n_bins_or_1 == 1 uses its single segment for every bin,
+ *              otherwise its n_bins_or_1 must equal n_bins
+ *   n_edges    E >= 2 thresholds per bin
+ *   t          float64[B][E], ascending in E: t[k][e] = pow(2 sin(ang_bins[k][e] / 2), 2.0) computed
+ *              on the host (trees.py:107-117, coordinates.py:277)
+ *   kernel     yawhip_kernel
+ * Pair (a in c1 segment (p,k), b in c2 segment (q,k)) belongs to fine bin e (0 <= e < E-1) iff
+ *       t[k][e] < s <= t[k][e+1],   s = ((ax-bx)^2 + (ay-by)^2) + (az-bz)^2   in float64 without FMA.
+ * Outputs (either may be NULL):
+ *   fine_counts  int64[n_jobs][B][E-1]  number of pairs            (bit exact)
+ *   fine_sums    float64[n_jobs][B][E-1] sum of w_a * w_b, a missing weight column counts as 1.0;
+ *                deterministic for a given library build and tile_r (no floating point atomics)
+ * When both catalogues are unweighted fine_sums, if requested, is the exact conversion of fine_counts.
+ */
+int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                       const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                       int64_t *fine_counts, double *fine_sums, yawhip_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YAWHIP_H */

@@ -1,0 +1,174 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes), against
+(1) golden vectors captured from the reference and (2) the CPU oracle on seeded inputs.
+Unweighted counts must be bit-identical; weighted sums within 1e-10 relative (north_star)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+RTOL_W = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from yet_another_wizz_amd import _lib
+
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _upload(ctx, cat):
+    from yet_another_wizz_amd import _lib
+
+    n_patches = (len(cat["off"]) - 1) // cat["nb"]
+    return _lib.DeviceCatalog(ctx, cat["x"], cat["y"], cat["z"], cat["w"], n_patches, cat["nb"], cat["off"])
+
+
+def _single(xyz, w):
+    return dict(x=xyz[:, 0].copy(), y=xyz[:, 1].copy(), z=xyz[:, 2].copy(), w=w, nb=1,
+                off=np.array([0, len(xyz)], dtype=np.int64))
+
+
+KERNELS = ["exact"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("tile_r", [1, 2, 4])
+def test_single_job_golden(ctx, kernel, tile_r):
+    from yet_another_wizz_amd import _lib
+
+    sj = load_golden("single_job.npz")
+    ctx.set_option("tile_r", tile_r)
+    cats = {}
+    for wname in ("uu", "ww", "wu", "uw"):
+        w1 = sj["w1"] if wname[0] == "w" else None
+        w2 = sj["w2"] if wname[1] == "w" else None
+        cats[wname] = (_upload(ctx, _single(sj["xyz1"], w1)), _upload(ctx, _single(sj["xyz2"], w2)))
+    n_checked = 0
+    for key in (str(k) for k in sj["case_names"]):
+        parts = key.split(".")
+        wname, kind = parts[1], parts[-1]
+        c1, c2 = cats[wname]
+        if kind == "auto":
+            c2 = c1
+        t = sj[key + ".t"][None, :]
+        counts, sums, stats = _lib.count_pairs(ctx, c1, c2, [[0, 0]], t, kernel=kernel, want_counts=True, want_sums=True)
+        exp = sj[key + ".fine"]
+        if wname == "uu":
+            assert np.array_equal(counts[0, 0].astype(np.float64), exp), key
+            assert np.array_equal(sums[0, 0], exp), key
+        else:
+            np.testing.assert_allclose(sums[0, 0], exp, rtol=RTOL_W, atol=0, err_msg=key)
+        assert stats.candidate_pairs == c1.n * c2.n
+        n_checked += 1
+    assert n_checked >= 40
+    ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_greatcircle_golden(ctx, kernel):
+    from yet_another_wizz_amd import _lib
+
+    gc = load_golden("greatcircle.npz")
+    DELTA = 1e-9
+    w = np.full(len(gc["xyz"]), 2.0)
+    tree = _upload(ctx, _single(gc["xyz"], w))
+    single = _upload(ctx, _single(gc["single_xyz"], np.array([2.0])))
+    for am in (1.0, 2.0, 10.0, 89.0):
+        hi = am + DELTA
+        lim = oracle.parse_ang_limits(np.deg2rad(hi - 1.0), np.deg2rad(hi))
+        ang_bins = oracle.ang_bins_for(lim, None, None)
+        t = oracle.thresholds_for(ang_bins)[None, :]
+        _, sums, _ = _lib.count_pairs(ctx, tree, single, [[0, 0]], t, kernel=kernel)
+        got = oracle.finalize(sums[0, 0], ang_bins, lim, None)
+        assert got == 16.0 and np.array_equal(got, gc[f"single_{int(am)}"])
+    # 88 one-degree annuli at once (E >= 8)
+    hi = np.arange(1.0, 89.0) + DELTA
+    lim = oracle.parse_ang_limits(np.deg2rad(hi - 1.0), np.deg2rad(hi))
+    ang_bins = oracle.ang_bins_for(lim, None, None)
+    t = oracle.thresholds_for(ang_bins)[None, :]
+    _, sums, _ = _lib.count_pairs(ctx, tree, single, [[0, 0]], t, kernel=kernel)
+    assert np.array_equal(oracle.finalize(sums[0, 0], ang_bins, lim, None), gc["bins_89"])
+    # self count: ordered pairs, self pairs excluded (reference test_trees.py:239-247)
+    utree = _upload(ctx, _single(gc["xyz"], None))
+    lim = oracle.parse_ang_limits(*(np.deg2rad([0.0, 1.0]) + DELTA))
+    ang_bins = oracle.ang_bins_for(lim, None, None)
+    t = oracle.thresholds_for(ang_bins)[None, :]
+    counts, _, _ = _lib.count_pairs(ctx, utree, utree, [[0, 0]], t, kernel=kernel)
+    assert counts[0, 0, 0] == 4 * 6 + 2 * (len(gc["xyz"]) - 6) == gc["dualtree"][0]
+
+
+def _random_catalog(rng, n, n_patches, nb, weighted, dense_box=2.0):
+    ra = np.deg2rad(rng.uniform(100.0, 100.0 + dense_box, n))
+    dec = np.arcsin(rng.uniform(np.sin(np.deg2rad(30.0)), np.sin(np.deg2rad(30.0 + dense_box)), n))
+    patch = rng.integers(0, n_patches, n)
+    patch[patch == 2] = 1  # patch 2 stays empty
+    z = rng.uniform(0.0, 1.0, n)
+    edges = np.linspace(0.1, 0.9, nb + 1) if nb > 1 else None
+    w = rng.uniform(0.5, 1.5, n) if weighted else None
+    return oracle.sort_catalog(ra, dec, z, w, patch, n_patches, edges, "right")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("nb2", [1, 5])
+@pytest.mark.parametrize("weights", ["uu", "wu", "uw", "ww"])
+def test_ragged_jobs_vs_oracle(ctx, kernel, nb2, weights):
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(99 + nb2)
+    P, B = 6, 5
+    c1 = _random_catalog(rng, 7000, P, B, weights[0] == "w")
+    c2 = _random_catalog(rng, 9000, P, nb2, weights[1] == "w")
+    jobs = np.array([(p, q) for p in range(P) for q in range(P) if (p + q) % 3 != 1], dtype=np.int32)
+    lim = oracle.parse_ang_limits(np.array([0.5, 2.0]) * np.pi / 10800, np.array([3.0, 8.0]) * np.pi / 10800)
+    t = np.stack([oracle.thresholds_for(oracle.ang_bins_for(lim * (1.0 + 0.1 * k), None, None)) for k in range(B)])
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    for tile_r in (0, 1, 4):
+        ctx.set_option("tile_r", tile_r)
+        counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+        assert np.array_equal(counts, exp_c)
+        if weights == "uu":
+            assert np.array_equal(sums, exp_c.astype(np.float64))
+        else:
+            np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+        assert exp_c.sum() > 1000
+    ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_empty_and_degenerate(ctx, kernel):
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(5)
+    c1 = _random_catalog(rng, 300, 3, 1, False)
+    empty = dict(x=np.empty(0), y=np.empty(0), z=np.empty(0), w=None, nb=1, off=np.zeros(4, dtype=np.int64))
+    d1, de = _upload(ctx, c1), _upload(ctx, empty)
+    t = np.array([[1e-8, 1e-6]])
+    counts, _, stats = _lib.count_pairs(ctx, d1, de, [[0, 0], [1, 1]], t, kernel=kernel)
+    assert counts.sum() == 0 and stats.candidate_pairs == 0
+    counts, _, _ = _lib.count_pairs(ctx, d1, d1, np.empty((0, 2), dtype=np.int32), t, kernel=kernel)
+    assert counts.shape == (0, 1, 1)
+    # many edges -> shared-histogram variant
+    edges = np.linspace(1e-9, 1e-5, 300)[None, :]
+    counts, _, _ = _lib.count_pairs(ctx, d1, d1, [[1, 1]], edges, kernel=kernel)
+    exp, _ = oracle.count_jobs(c1, c1, [[1, 1]], edges)
+    assert np.array_equal(counts, exp)
+
+
+def test_errors(ctx):
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(6)
+    c1 = _random_catalog(rng, 100, 3, 1, False)
+    c4 = _random_catalog(rng, 100, 4, 1, False)
+    d1, d4 = _upload(ctx, c1), _upload(ctx, c4)
+    with pytest.raises(_lib.YawhipError, match="patch counts differ"):
+        _lib.count_pairs(ctx, d1, d4, [[0, 0]], np.array([[1e-6, 1e-5]]))
+    with pytest.raises(_lib.YawhipError, match="ascending"):
+        _lib.count_pairs(ctx, d1, d1, [[0, 0]], np.array([[1e-5, 1e-6]]))
+    with pytest.raises(_lib.YawhipError, match="patch id"):
+        _lib.count_pairs(ctx, d1, d1, [[0, 7]], np.array([[1e-6, 1e-5]]))

@@ -1,0 +1,223 @@
+"""ctypes binding of ``libyawhip.so`` (C ABI: ``include/yawhip.h``).
+
+There is deliberately no CPU fallback: if the shared object is missing or no MI355X is visible the
+calls raise ``YawhipError`` -- a measurement must never silently run somewhere else.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libyawhip.so")
+
+KERNEL_AUTO, KERNEL_EXACT, KERNEL_FILTER, KERNEL_SWEEP = 0, 1, 2, 3
+KERNEL_IDS = {"auto": KERNEL_AUTO, "exact": KERNEL_EXACT, "filter": KERNEL_FILTER, "sweep": KERNEL_SWEEP}
+
+# every symbol include/yawhip.h declares (tests check the export list against this)
+ABI_SYMBOLS = (
+    "yawhip_last_error",
+    "yawhip_abi_version",
+    "yawhip_device_count",
+    "yawhip_ctx_create",
+    "yawhip_ctx_destroy",
+    "yawhip_ctx_set_option",
+    "yawhip_catalog_upload",
+    "yawhip_catalog_free",
+    "yawhip_catalog_device_bytes",
+    "yawhip_count_pairs",
+)
+
+
+class YawhipError(RuntimeError):
+    """Raised when libyawhip.so is unavailable or a call into it fails."""
+
+
+class _Stats(ctypes.Structure):
+    _fields_ = [
+        ("candidate_pairs", ctypes.c_int64),
+        ("evaluated_pairs", ctypes.c_int64),
+        ("algorithmic_bytes", ctypes.c_int64),
+        ("n_workgroups", ctypes.c_int64),
+        ("n_launches", ctypes.c_int32),
+        ("kernel_used", ctypes.c_int32),
+        ("kernel_ms", ctypes.c_double),
+        ("total_ms", ctypes.c_double),
+    ]
+
+
+@dataclass
+class CountStats:
+    candidate_pairs: int = 0
+    evaluated_pairs: int = 0
+    algorithmic_bytes: int = 0
+    n_workgroups: int = 0
+    n_launches: int = 0
+    kernel_used: int = 0
+    kernel_ms: float = 0.0
+    total_ms: float = 0.0
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libyawhip.so and declare its prototypes. Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YawhipError(
+            f"{LIB_PATH} not found: build it with `python -m yet_another_wizz_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the pair-count path."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as err:  # e.g. libamdhip64 missing
+        raise YawhipError(f"cannot load {LIB_PATH}: {err}") from err
+    lib.yawhip_last_error.restype = ctypes.c_char_p
+    lib.yawhip_last_error.argtypes = []
+    lib.yawhip_abi_version.restype = ctypes.c_int
+    lib.yawhip_abi_version.argtypes = []
+    lib.yawhip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    lib.yawhip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+    lib.yawhip_ctx_destroy.argtypes = [_vp]
+    lib.yawhip_ctx_set_option.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int64]
+    lib.yawhip_catalog_upload.argtypes = [
+        _vp, ctypes.c_int64, _dp, _dp, _dp, _dp, ctypes.c_int32, ctypes.c_int32, _i64p, ctypes.POINTER(_vp),
+    ]
+    lib.yawhip_catalog_free.argtypes = [_vp]
+    lib.yawhip_catalog_device_bytes.argtypes = [_vp, _i64p]
+    lib.yawhip_count_pairs.argtypes = [
+        _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
+        _i64p, _dp, ctypes.POINTER(_Stats),
+    ]
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if name != "yawhip_last_error":
+            fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().yawhip_last_error()
+        raise YawhipError(f"{what} failed (status {rc}): {msg.decode() if msg else 'unknown error'}")
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    rc = load_library().yawhip_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Context:
+    """One GPU (one HIP stream). ``yawhip_ctx`` of include/yawhip.h."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp()
+        _check(load_library().yawhip_ctx_create(int(device), ctypes.byref(self._h)), "yawhip_ctx_create")
+        self.device = int(device)
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(load_library().yawhip_ctx_set_option(self._h, key.encode(), int(value)), "yawhip_ctx_set_option")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            load_library().yawhip_ctx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceCatalog:
+    """SoA catalogue resident in HBM, sorted by (patch, bin). ``yawhip_catalog``."""
+
+    def __init__(self, ctx: Context, x, y, z, w, n_patches: int, n_bins_or_1: int, offsets):
+        x, y, z, w = _f64(x), _f64(y), _f64(z), _f64(w)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(x)
+        if not (len(y) == n and len(z) == n and (w is None or len(w) == n)):
+            raise ValueError("catalogue columns differ in length")
+        if len(offsets) != n_patches * n_bins_or_1 + 1:
+            raise ValueError("offsets must have n_patches * n_bins_or_1 + 1 entries")
+        self.ctx = ctx  # keep the context alive
+        self.n, self.n_patches, self.n_bins = n, int(n_patches), int(n_bins_or_1)
+        self.weighted = w is not None
+        self._h = _vp()
+        _check(
+            load_library().yawhip_catalog_upload(
+                ctx._h, n, _ptr(x, _dp), _ptr(y, _dp), _ptr(z, _dp), _ptr(w, _dp), self.n_patches, self.n_bins,
+                _ptr(offsets, _i64p), ctypes.byref(self._h),
+            ),
+            "yawhip_catalog_upload",
+        )
+
+    @property
+    def device_bytes(self) -> int:
+        b = ctypes.c_int64(0)
+        _check(load_library().yawhip_catalog_device_bytes(self._h, ctypes.byref(b)), "yawhip_catalog_device_bytes")
+        return b.value
+
+    def free(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            load_library().yawhip_catalog_free(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def count_pairs(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresholds, *, kernel="auto",
+                want_counts=None, want_sums=None):
+    """Run ``yawhip_count_pairs``.
+
+    jobs: int[n_jobs,2]; thresholds: f64[B,E]. Returns (counts int64[n_jobs,B,E-1] | None,
+    sums f64[n_jobs,B,E-1] | None, CountStats)."""
+    jobs = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2)
+    t = np.ascontiguousarray(thresholds, dtype=np.float64)
+    if t.ndim != 2:
+        raise ValueError("thresholds must be [n_bins, n_edges]")
+    n_bins, n_edges = t.shape
+    weighted = c1.weighted or c2.weighted
+    if want_counts is None:
+        want_counts = not weighted
+    if want_sums is None:
+        want_sums = weighted
+    shape = (len(jobs), n_bins, max(n_edges - 1, 0))
+    counts = np.zeros(shape, dtype=np.int64) if want_counts else None
+    sums = np.zeros(shape, dtype=np.float64) if want_sums else None
+    st = _Stats()
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    _check(
+        load_library().yawhip_count_pairs(
+            ctx._h, c1._h, c2._h, len(jobs), _ptr(jobs, _i32p), n_bins, n_edges, _ptr(t, _dp), kid,
+            _ptr(counts, _i64p), _ptr(sums, _dp), ctypes.byref(st),
+        ),
+        "yawhip_count_pairs",
+    )
+    stats = CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
+    return counts, sums, stats

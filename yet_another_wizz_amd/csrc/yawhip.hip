@@ -1,0 +1,593 @@
+// yawhip.hip -- MI355X (gfx950 / CDNA4) angular pair counting behind the C ABI of include/yawhip.h.
+//
+// Replaces the per-job loop of PatchLinkage.count_pairs (reference src/yaw/correlation/measurements.py:344-364):
+// for each linked patch pair (p,q) and redshift bin k it counts, per fine angular bin e, the object
+// pairs with  t[k][e] < s <= t[k][e+1],  s = ((ax-bx)^2 + (ay-by)^2) + (az-bz)^2  in float64 without
+// FMA -- the predicate scipy's KDTree.count_neighbors applies behind AngularTree.count
+// (src/yaw/catalog/trees.py:303-362).
+//
+// Design (wave64, no MFMA -- K=3 distances are not a contraction and bit parity forbids a dot-product rewrite):
+//   * catalogues live in HBM as SoA float64 columns x,y,z,(w), sorted by (patch, z-bin) with a CSR
+//     offset table; every column load is a fully coalesced 512 B per wave;
+//   * work item = (job, bin, lane tile): a 256-thread workgroup keeps TILE = 256*R objects of the
+//     c2 segment in registers (R per lane) and streams the c1 segment through LDS in 256-object
+//     stages (register-staged double buffer), reading each streamed object as a wave-wide LDS broadcast;
+//   * per streamed object: 8 FP64 VALU ops + 1 compare per lane-object; a wave ballot of "s <= t_max"
+//     skips the histogram update for the >99.9 % of iterations without any pair inside the outer edge;
+//   * counters: per-lane private LDS histograms (no atomics in the loop), fixed-order tree reduction
+//     at the end of the item; unweighted results are added with 64-bit integer atomics (exact,
+//     order independent), weighted results go to a per-item slab that a second kernel sums in item
+//     order, so weighted sums are bit-reproducible run to run.
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (see yet_another_wizz_amd/build.py).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "yawhip.h"
+
+namespace {
+
+constexpr int WG = 256;      // threads per workgroup = 4 waves of 64
+constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
+constexpr int MAX_EDGES = 512;
+constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                         \
+    } while (0)
+
+struct CatView {
+    const double *x, *y, *z, *w;  // w may be null
+    const int64_t *off;           // [P*nb+1]
+    int nb;
+};
+
+struct alignas(16) Obj {  // one streamed object in LDS: two 16-byte broadcast reads
+    double x, y, z, w;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Exact FP64 brute-force count.
+//   R         objects per lane (lane tile = 256*R objects of the c2 segment)
+//   WEIGHTED  accumulate w_a*w_b in float64 (else count in uint32)
+//   PRIVATE   per-lane private LDS histogram (deterministic); else one shared LDS histogram per
+//             workgroup updated with LDS atomics (only used when E is too large for private ones)
+// ------------------------------------------------------------------------------------------------
+template <int R, bool WEIGHTED, bool PRIVATE>
+__global__ __launch_bounds__(WG) void k_count_exact(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
+                                                    const int64_t *__restrict__ prefix, int n_slots, int n_bins,
+                                                    int n_edges, const double *__restrict__ t, int64_t item_base,
+                                                    unsigned long long *__restrict__ out_counts,
+                                                    double *__restrict__ partials) {
+    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Obj *stage = reinterpret_cast<Obj *>(lds_raw);                                  // [2][STAGE]
+    double *thr = reinterpret_cast<double *>(lds_raw + 2 * STAGE * sizeof(Obj));    // [n_edges]
+    HistT *hist = reinterpret_cast<HistT *>(thr + ((n_edges + 1) & ~1));            // [nf][WG] or [nf]
+
+    const int tid = threadIdx.x;
+    const int nf = n_edges - 1;
+    const int64_t item = item_base + blockIdx.x;
+
+    // slot = largest s with prefix[s] <= item   (uniform binary search)
+    int lo = 0, hi = n_slots;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int slot = lo;
+    const int job = slot / n_bins, k = slot - job * n_bins;
+    const int p = jobs[2 * job], q = jobs[2 * job + 1];
+    const int k1 = c1.nb == 1 ? 0 : k, k2 = c2.nb == 1 ? 0 : k;
+    const int64_t b0 = c1.off[(int64_t)p * c1.nb + k1], b1 = c1.off[(int64_t)p * c1.nb + k1 + 1];
+    const int64_t a_seg0 = c2.off[(int64_t)q * c2.nb + k2], a_seg1 = c2.off[(int64_t)q * c2.nb + k2 + 1];
+    const int64_t a0 = a_seg0 + (item - prefix[slot]) * (int64_t)(WG * R);
+
+    // lane objects (c2 side) -> registers; padded lanes are parked far away
+    double ax[R], ay[R], az[R], aw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = a0 + (int64_t)r * WG + tid;
+        const bool ok = i < a_seg1;
+        ax[r] = ok ? c2.x[i] : PAD_COORD;
+        ay[r] = ok ? c2.y[i] : PAD_COORD;
+        az[r] = ok ? c2.z[i] : PAD_COORD;
+        aw[r] = (WEIGHTED && ok && c2.w) ? c2.w[i] : (ok ? 1.0 : 0.0);
+    }
+
+    for (int e = tid; e < n_edges; e += WG) thr[e] = t[(int64_t)k * n_edges + e];
+    if (PRIVATE) {
+        for (int j = 0; j < nf; ++j) hist[j * WG + tid] = HistT(0);
+    } else {
+        for (int j = tid; j < nf; j += WG) hist[j] = HistT(0);
+    }
+    const double tmax = t[(int64_t)k * n_edges + n_edges - 1];
+
+    const int64_t nb_total = b1 - b0;
+    const int nstages = (int)((nb_total + STAGE - 1) / STAGE);
+
+    // stage 0
+    {
+        const int64_t i = b0 + tid;
+        Obj o;
+        const bool ok = i < b1;
+        o.x = ok ? c1.x[i] : 0.0; o.y = ok ? c1.y[i] : 0.0; o.z = ok ? c1.z[i] : 0.0;
+        o.w = (WEIGHTED && ok && c1.w) ? c1.w[i] : 1.0;
+        stage[tid] = o;
+    }
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+        const Obj *cur = stage + (st & 1) * STAGE;
+        // issue the next stage's global loads early; they land in registers while we compute
+        Obj nxt;
+        const bool have_next = st + 1 < nstages;
+        if (have_next) {
+            const int64_t i = b0 + (int64_t)(st + 1) * STAGE + tid;
+            const bool ok = i < b1;
+            nxt.x = ok ? c1.x[i] : 0.0; nxt.y = ok ? c1.y[i] : 0.0; nxt.z = ok ? c1.z[i] : 0.0;
+            nxt.w = (WEIGHTED && ok && c1.w) ? c1.w[i] : 1.0;
+        }
+        const int64_t left = nb_total - (int64_t)st * STAGE;
+        const int n = left < STAGE ? (int)left : STAGE;
+
+        for (int i = 0; i < n; ++i) {
+            const Obj b = cur[i];  // wave-wide broadcast read
+            double s[R];
+            bool any = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const double dx = ax[r] - b.x;
+                const double dy = ay[r] - b.y;
+                const double dz = az[r] - b.z;
+                const double xx = dx * dx;
+                const double yy = dy * dy;
+                const double zz = dz * dz;
+                const double sxy = xx + yy;
+                s[r] = sxy + zz;
+                any |= (s[r] <= tmax);
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // rare: some lane has a pair inside the outer edge
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (s[r] <= tmax) {
+                        int cnt = 0;
+                        for (int e = 0; e < n_edges; ++e) cnt += (s[r] > thr[e]) ? 1 : 0;
+                        if (cnt > 0) {  // t[cnt-1] < s <= t[cnt]
+                            const HistT v = WEIGHTED ? HistT(aw[r] * b.w) : HistT(1);
+                            if (PRIVATE) hist[(cnt - 1) * WG + tid] += v;
+                            else atomicAdd(&hist[cnt - 1], v);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (have_next) stage[((st + 1) & 1) * STAGE + tid] = nxt;
+        __syncthreads();
+    }
+
+    // fixed-order tree reduction of the private histograms
+    if (PRIVATE) {
+        for (int stride = WG / 2; stride > 0; stride >>= 1) {
+            if (tid < stride)
+                for (int j = 0; j < nf; ++j) hist[j * WG + tid] += hist[j * WG + tid + stride];
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < nf; j += WG) {
+        const HistT v = PRIVATE ? hist[j * WG] : hist[j];
+        if (WEIGHTED) partials[item * nf + j] = (double)v;
+        else if (v != HistT(0)) atomicAdd(&out_counts[(int64_t)slot * nf + j], (unsigned long long)v);
+    }
+}
+
+// Sum the per-item slabs of every (job,bin) slot in item order (deterministic).
+__global__ void k_reduce_partials(const double *__restrict__ partials, const int64_t *__restrict__ prefix,
+                                  int n_slots, int nf, double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_slots * nf) return;
+    const int slot = (int)(idx / nf), j = (int)(idx - (int64_t)slot * nf);
+    double acc = 0.0;
+    for (int64_t it = prefix[slot]; it < prefix[slot + 1]; ++it) acc += partials[it * nf + j];
+    out[idx] = acc;
+}
+
+__global__ void k_counts_to_double(const unsigned long long *__restrict__ in, double *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+template <typename T>
+struct DevBuf {  // grow-only device workspace
+    T *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ptr), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct yawhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int tile_r = 0;          // 0 = auto
+    int default_kernel = YAWHIP_KERNEL_AUTO;
+    int lds_limit = 160 * 1024;
+    DevBuf<int32_t> d_jobs;
+    DevBuf<int64_t> d_prefix;
+    DevBuf<double> d_t;
+    DevBuf<unsigned long long> d_counts;
+    DevBuf<double> d_sums;
+    DevBuf<double> d_partials;
+};
+
+struct yawhip_catalog {
+    yawhip_ctx *ctx = nullptr;
+    int64_t n = 0;
+    int32_t n_patches = 0, nb = 1;
+    double *x = nullptr, *y = nullptr, *z = nullptr, *w = nullptr;
+    int64_t *off = nullptr;
+    std::vector<int64_t> h_off;
+    int64_t device_bytes = 0;
+};
+
+namespace {
+
+CatView view_of(const yawhip_catalog *c) { return CatView{c->x, c->y, c->z, c->w, c->off, c->nb}; }
+
+template <int R, bool W, bool P>
+hipError_t launch_exact(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots, int n_bins,
+                        int n_edges, int64_t n_items, size_t lds_bytes) {
+    auto kern = k_count_exact<R, W, P>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t max_grid = 1ll << 30;
+    for (int64_t base = 0; base < n_items; base += max_grid) {
+        const int64_t g = std::min(max_grid, n_items - base);
+        hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WG), lds_bytes, ctx->stream, view_of(c1), view_of(c2),
+                           ctx->d_jobs.ptr, ctx->d_prefix.ptr, n_slots, n_bins, n_edges, ctx->d_t.ptr, base,
+                           ctx->d_counts.ptr, ctx->d_partials.ptr);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+template <bool W, bool P>
+hipError_t launch_exact_r(int r, yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots,
+                          int n_bins, int n_edges, int64_t n_items, size_t lds) {
+    switch (r) {
+        case 1: return launch_exact<1, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+        case 2: return launch_exact<2, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+        default: return launch_exact<4, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+    }
+}
+
+inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
+    const int kk = c->nb == 1 ? 0 : k;
+    const int64_t i = (int64_t)patch * c->nb + kk;
+    return c->h_off[i + 1] - c->h_off[i];
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char *yawhip_last_error(void) { return g_last_error.c_str(); }
+int yawhip_abi_version(void) { return YAWHIP_ABI_VERSION; }
+
+int yawhip_device_count(int *n) {
+    if (!n) return fail(YAWHIP_ERR_INVALID, "yawhip_device_count: n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(YAWHIP_ERR_NO_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return YAWHIP_OK;
+}
+
+int yawhip_ctx_create(int device_id, yawhip_ctx **out) {
+    if (!out) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_create: out is NULL");
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0)
+        return fail(YAWHIP_ERR_NO_DEVICE, "no HIP device visible (the HIP path is mandatory; there is no CPU fallback)");
+    if (device_id < 0 || device_id >= c)
+        return fail(YAWHIP_ERR_NO_DEVICE, "device id %d out of range [0,%d)", device_id, c);
+    HIP_TRY(hipSetDevice(device_id));
+    yawhip_ctx *ctx = new (std::nothrow) yawhip_ctx();
+    if (!ctx) return fail(YAWHIP_ERR_OOM, "host allocation failed");
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(YAWHIP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.sharedMemPerBlock > 0)
+        ctx->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    *out = ctx;
+    return YAWHIP_OK;
+}
+
+int yawhip_ctx_destroy(yawhip_ctx *ctx) {
+    if (!ctx) return YAWHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->d_jobs.release();
+    ctx->d_prefix.release();
+    ctx->d_t.release();
+    ctx->d_counts.release();
+    ctx->d_sums.release();
+    ctx->d_partials.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return YAWHIP_OK;
+}
+
+int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_set_option: NULL argument");
+    if (!strcmp(key, "tile_r")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4)
+            return fail(YAWHIP_ERR_INVALID, "tile_r must be 0 (auto), 1, 2 or 4");
+        ctx->tile_r = (int)value;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "kernel")) {
+        if (value < YAWHIP_KERNEL_AUTO || value > YAWHIP_KERNEL_SWEEP)
+            return fail(YAWHIP_ERR_INVALID, "unknown kernel id %lld", (long long)value);
+        ctx->default_kernel = (int)value;
+        return YAWHIP_OK;
+    }
+    return fail(YAWHIP_ERR_INVALID, "unknown option '%s'", key);
+}
+
+int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+                          const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
+                          yawhip_catalog **out) {
+    if (!out) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: ctx is NULL");
+    if (n < 0 || n_patches <= 0 || n_bins_or_1 <= 0 || !offsets || (n > 0 && (!x || !y || !z)))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: bad sizes or NULL columns");
+    const int64_t nseg = (int64_t)n_patches * n_bins_or_1;
+    if (offsets[0] != 0 || offsets[nseg] != n) return fail(YAWHIP_ERR_INVALID, "offsets must start at 0 and end at n");
+    for (int64_t i = 0; i < nseg; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(YAWHIP_ERR_INVALID, "offsets must be non-decreasing");
+    HIP_TRY(hipSetDevice(ctx->device));
+    yawhip_catalog *c = new (std::nothrow) yawhip_catalog();
+    if (!c) return fail(YAWHIP_ERR_OOM, "host allocation failed");
+    c->ctx = ctx;
+    c->n = n;
+    c->n_patches = n_patches;
+    c->nb = n_bins_or_1;
+    c->h_off.assign(offsets, offsets + nseg + 1);
+    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->x), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->y), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->z), col);
+    if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->w), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->off), (size_t)(nseg + 1) * sizeof(int64_t));
+    if (e == hipSuccess && n > 0) {
+        e = hipMemcpyAsync(c->x, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->z, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && w)
+            e = hipMemcpyAsync(c->w, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(c->off, offsets, (size_t)(nseg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        yawhip_catalog_free(c);
+        return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload failed: %s",
+                    hipGetErrorString(e));
+    }
+    c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
+    *out = c;
+    return YAWHIP_OK;
+}
+
+int yawhip_catalog_free(yawhip_catalog *c) {
+    if (!c) return YAWHIP_OK;
+    if (c->ctx) (void)hipSetDevice(c->ctx->device);
+    if (c->x) (void)hipFree(c->x);
+    if (c->y) (void)hipFree(c->y);
+    if (c->z) (void)hipFree(c->z);
+    if (c->w) (void)hipFree(c->w);
+    if (c->off) (void)hipFree(c->off);
+    delete c;
+    return YAWHIP_OK;
+}
+
+int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes) {
+    if (!cat || !bytes) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_device_bytes: NULL argument");
+    *bytes = cat->device_bytes;
+    return YAWHIP_OK;
+}
+
+int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                       const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                       int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: NULL handle");
+    if (c1->ctx != ctx || c2->ctx != ctx) return fail(YAWHIP_ERR_MISMATCH, "catalogues belong to another context");
+    if (c1->n_patches != c2->n_patches)
+        return fail(YAWHIP_ERR_MISMATCH, "patch counts differ (%d vs %d)", c1->n_patches, c2->n_patches);
+    if (n_jobs < 0 || n_bins <= 0 || n_edges < 2 || n_edges > MAX_EDGES || !t || (n_jobs > 0 && !jobs))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: bad sizes (n_jobs=%d n_bins=%d n_edges=%d, max edges %d)",
+                    n_jobs, n_bins, n_edges, MAX_EDGES);
+    if ((c1->nb != 1 && c1->nb != n_bins) || (c2->nb != 1 && c2->nb != n_bins))
+        return fail(YAWHIP_ERR_MISMATCH, "catalogue bin counts (%d, %d) do not fit n_bins=%d", c1->nb, c2->nb, n_bins);
+    for (int k = 0; k < n_bins; ++k)
+        for (int e = 0; e < n_edges; ++e) {
+            const double v = t[(size_t)k * n_edges + e];
+            if (!(v >= 0.0) || (e > 0 && !(v >= t[(size_t)k * n_edges + e - 1])))
+                return fail(YAWHIP_ERR_INVALID, "thresholds of bin %d are not ascending non-negative numbers", k);
+        }
+    for (int j = 0; j < n_jobs; ++j)
+        if (jobs[2 * j] < 0 || jobs[2 * j] >= c1->n_patches || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= c1->n_patches)
+            return fail(YAWHIP_ERR_INVALID, "job %d has a patch id outside [0,%d)", j, c1->n_patches);
+    if (kernel == YAWHIP_KERNEL_AUTO) kernel = ctx->default_kernel;
+    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_EXACT;
+    if (kernel != YAWHIP_KERNEL_EXACT)
+        return fail(YAWHIP_ERR_INVALID, "kernel %d is not available in this build", kernel);
+
+    const int nf = n_edges - 1;
+    const int64_t n_slots = (int64_t)n_jobs * n_bins;
+    const int64_t n_out = n_slots * nf;
+    const bool weighted = (c1->w != nullptr) || (c2->w != nullptr);
+    if (n_out == 0) return YAWHIP_OK;
+    if (n_slots > (1ll << 30)) return fail(YAWHIP_ERR_INVALID, "too many (job,bin) slots");
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    // tile size: objects per lane. Larger tiles amortise the streamed-object read; small segments
+    // prefer small tiles so that padded lanes do not dominate.
+    int R = ctx->tile_r;
+    if (R == 0) {
+        int64_t max_seg = 0;
+        for (int j = 0; j < n_jobs; ++j)
+            for (int k = 0; k < (c2->nb == 1 ? 1 : n_bins); ++k) max_seg = std::max(max_seg, seg_len(c2, jobs[2 * j + 1], k));
+        R = max_seg >= 8 * WG * 4 ? 4 : (max_seg >= 4 * WG * 2 ? 2 : 1);
+    }
+    const int64_t tile = (int64_t)WG * R;
+
+    // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles
+    std::vector<int64_t> prefix((size_t)n_slots + 1);
+    int64_t n_items = 0, cand = 0, abytes = 0;
+    const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
+    for (int j = 0; j < n_jobs; ++j)
+        for (int k = 0; k < n_bins; ++k) {
+            const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
+            prefix[(size_t)j * n_bins + k] = n_items;
+            if (n1 > 0 && n2 > 0) {
+                n_items += (n2 + tile - 1) / tile;
+                cand += n1 * n2;
+                abytes += n1 * obj_bytes1 + n2 * obj_bytes2;
+            }
+        }
+    prefix[(size_t)n_slots] = n_items;
+
+    const bool want_counts = fine_counts != nullptr;
+    const bool want_sums = fine_sums != nullptr;
+    const bool run_weighted = weighted && want_sums;
+    const bool run_unweighted = want_counts || (!weighted && want_sums);
+
+    HIP_TRY(ctx->d_jobs.reserve((size_t)2 * n_jobs));
+    HIP_TRY(ctx->d_prefix.reserve((size_t)n_slots + 1));
+    HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
+    HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
+    HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
+    if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * nf));
+    HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice,
+                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_sums.ptr, 0, sizeof(double) * n_out, ctx->stream));
+
+    // LDS: two stages + thresholds + histogram(s)
+    const size_t lds_fixed = 2 * STAGE * sizeof(Obj) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
+    auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
+    int launches = 0;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (n_items > 0) {
+        if (run_unweighted) {
+            const bool priv = lds_for(false, true) <= (size_t)ctx->lds_limit;
+            hipError_t e = priv ? launch_exact_r<false, true>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(false, true))
+                                : launch_exact_r<false, false>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(false, false));
+            HIP_TRY(e);
+            ++launches;
+        }
+        if (run_weighted) {
+            const bool priv = lds_for(true, true) <= (size_t)ctx->lds_limit;
+            hipError_t e = priv ? launch_exact_r<true, true>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(true, true))
+                                : launch_exact_r<true, false>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(true, false));
+            HIP_TRY(e);
+            ++launches;
+            const int thr = 256;
+            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_out + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_slots, nf, ctx->d_sums.ptr);
+            HIP_TRY(hipGetLastError());
+            ++launches;
+        }
+    }
+    if (!weighted && want_sums) {
+        const int thr = 256;
+        hipLaunchKernelGGL(k_counts_to_double, dim3((unsigned)((n_out + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                           ctx->d_counts.ptr, ctx->d_sums.ptr, n_out);
+        HIP_TRY(hipGetLastError());
+        ++launches;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    if (want_counts)
+        HIP_TRY(hipMemcpyAsync(fine_counts, ctx->d_counts.ptr, sizeof(int64_t) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    if (want_sums)
+        HIP_TRY(hipMemcpyAsync(fine_sums, ctx->d_sums.ptr, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (stats) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->candidate_pairs = cand;
+        stats->evaluated_pairs = cand * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
+        stats->algorithmic_bytes = abytes;
+        stats->n_workgroups = n_items;
+        stats->n_launches = launches;
+        stats->kernel_used = kernel;
+        stats->kernel_ms = ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    return YAWHIP_OK;
+}
+
+}  // extern "C"
