@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the angular pair-counting hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: the DD pair count of a
+cross-correlation (``PatchLinkage.count_pairs(reference, unknown)``, the call the reference makes at
+src/yaw/correlation/measurements.py:623) over every linked patch pair and redshift bin, with both
+catalogues already resident in HBM.  The workload is the configuration BASELINE.json quotes the
+metric on: 10M reference x 10M unknown objects, uniform full sky, 30 linear z-bins, 64 patches,
+one 1-10 arcmin annulus.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+
+Rank 0 prints ONE JSON line. ``value`` = candidate pairs (sum over linked patch pairs and bins of
+N1*N2, what a brute-force count must decide) of the whole job divided by the slowest rank's time.
+With N ranks the fixed job list is sharded (strong scaling) and the result tensor all-reduced.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6            # MI355X FP64 vector peak incl. FMA (AMD spec)
+FP32_VECTOR_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-ref", type=float, default=10e6)
+    ap.add_argument("--n-unk", type=float, default=10e6)
+    ap.add_argument("--patches", type=int, default=64)
+    ap.add_argument("--zbins", type=int, default=30)
+    ap.add_argument("--kernel", default="auto", choices=["auto", "exact", "filter", "sweep"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------- inputs
+def fibonacci_centers(num):
+    """num near-uniform points on the sphere (patch centres for the full-sky configs)."""
+    i = np.arange(num) + 0.5
+    dec = np.arcsin(1.0 - 2.0 * i / num)
+    ra = (np.pi * (1.0 + 5.0**0.5) * i) % (2.0 * np.pi)
+    return np.column_stack([ra, dec])
+
+
+def uniform_sky(seed, n):
+    """ra ~ U(0, 2pi), dec = arcsin(U(-1, 1)): the recipe of the reference's BoxRandoms
+    (src/yaw/randoms.py:246-259) on the full sky. Radian."""
+    rng = np.random.default_rng(seed)
+    return rng.uniform(0.0, 2.0 * np.pi, n), np.arcsin(rng.uniform(-1.0, 1.0, n)), rng
+
+
+def make_catalogs(args):
+    import yet_another_wizz_amd as yaw
+
+    centers = yaw.AngularCoordinates(fibonacci_centers(args.patches))
+    ra, dec, rng = uniform_sky(101, int(args.n_ref))
+    ref = yaw.Catalog.from_arrays(ra, dec, redshifts=rng.uniform(0.1, 1.0, len(ra)), patch_centers=centers, degrees=False)
+    ra, dec, _ = uniform_sky(202, int(args.n_unk))
+    unk = yaw.Catalog.from_arrays(ra, dec, patch_centers=centers, degrees=False)
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
+    return config, ref, unk
+
+
+# ---------------------------------------------------------------------------------------------- cpu baseline
+def cpu_baseline(links, ref, unk, budget_s):
+    """Time the CPU oracle (oracle/paircount_oracle.c, brute force, OpenMP over the host's cores) on a
+    bounded sample of the same workload, and check the GPU result on that sample against it."""
+    from oracle import oracle
+    from yet_another_wizz_amd import engine
+    from yet_another_wizz_amd.measurements import angular_plans, threshold_table
+
+    oracle.build()
+    l1, l2 = ref._active_layout, unk._active_layout
+    jobs = links.get_patch_pairs(ref, unk)
+    t = threshold_table(angular_plans(links.config))
+
+    def as_cat(layout):
+        return dict(x=layout.x, y=layout.y, z=layout.z, w=layout.w, nb=layout.num_bins, off=layout.offsets)
+
+    c1, c2 = as_cat(l1), as_cat(l2)
+    sizes1, sizes2 = l1.segment_sizes(), l2.segment_sizes()
+    cost = sizes1[jobs[:, 0]].sum(axis=1).astype(np.float64) * sizes2[jobs[:, 1]].sum(axis=1)
+    # calibrate on a thin slice (one z-bin of one job), then size the sample to the budget
+    t0 = time.perf_counter()
+    oracle.count_jobs(c1, c2, jobs[:1], t[:1])
+    calib = time.perf_counter() - t0
+    rate = max(float(sizes1[jobs[0, 0], 0]) * float(sizes2[jobs[0, 1]].sum()) / max(calib, 1e-6), 1.0)
+    n_sample = int(np.clip(np.searchsorted(np.cumsum(cost), rate * budget_s), 1, len(jobs)))
+    sample = jobs[:n_sample]
+    t0 = time.perf_counter()
+    exp_counts, _ = oracle.count_jobs(c1, c2, sample, t)
+    secs = time.perf_counter() - t0
+    got, _ = engine.count_fine(l1, l2, sample, t)
+    parity = bool(np.array_equal(got, exp_counts.astype(np.float64)))
+    pairs = float(cost[:n_sample].sum())
+    return dict(
+        value=pairs / secs, unit="pairs/s", cores=oracle.num_threads(), kind="port",
+        sample=f"first {n_sample} of {len(jobs)} linked patch pairs, all {t.shape[0]} z-bins: "
+               f"{pairs:.3e} candidate pairs in {secs:.1f} s (brute-force C oracle, OpenMP)",
+        parity_with_gpu=parity,
+    )
+
+
+# ---------------------------------------------------------------------------------------------- main
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pair-count path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from yet_another_wizz_amd import PatchLinkage, engine
+
+    engine.default_kernel = args.kernel
+    t_setup = time.perf_counter()
+    config, ref, unk = make_catalogs(args)
+    ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    unk.build_trees(None)
+    links = PatchLinkage.from_catalogs(config, ref, unk)
+    setup_s = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        links.count_pairs(ref, unk)
+        return links.last_stats
+
+    for _ in range(max(args.warmup, 0)):  # first call also uploads the catalogues to HBM
+        step()
+    if args.warmup == 0:  # inputs must be resident before the timed region
+        engine.device_catalog(ref._active_layout)
+        engine.device_catalog(unk._active_layout)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, stats = 0.0, None
+    for _ in range(args.steps):
+        stats = step()
+        kernel_ms += stats.kernel_ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # whole-job numbers: max time over ranks, sum of per-rank work
+    tens = torch.tensor([elapsed, kernel_ms / max(args.steps, 1)], dtype=torch.float64, device="cuda")
+    work = torch.tensor([float(stats.candidate_pairs), float(stats.evaluated_pairs), float(stats.algorithmic_bytes),
+                         float(stats.n_workgroups)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tens, op=dist.ReduceOp.MAX)
+        dist.all_reduce(work, op=dist.ReduceOp.SUM)
+    elapsed, kernel_ms_step = tens.tolist()
+    cand, evaluated, abytes, n_wg = work.tolist()
+
+    if rank == 0:
+        value = cand * args.steps / elapsed
+        # dominant kernel: the count kernel. Algorithmic work per evaluated pair = 8 FP64 flop
+        # (3 sub, 3 mul, 2 add; the compares are not counted), exact mode forbids FMA, so the
+        # ceiling is half of the FP64 vector peak. Rank 0's launch is representative.
+        k_s = max(stats.kernel_ms, 1e-9) / 1e3
+        kernel_name = {1: "exact", 2: "filter", 3: "sweep"}.get(stats.kernel_used, str(stats.kernel_used))
+        achieved_tflops = stats.evaluated_pairs * 8.0 / k_s / 1e12
+        peak = FP64_VECTOR_PEAK_TFLOPS / 2.0
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as f:
+                traffic = json.load(f).get(f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}")
+        roofline = dict(
+            bound="valu_fp64", achieved=achieved_tflops, peak=peak, unit="TFLOP/s", frac=achieved_tflops / peak,
+            traffic=traffic,
+            note="FP64 vector ALU bound, not HBM/MFMA (SURVEY.md 8(d)): 8 non-FMA FP64 flop per evaluated pair",
+            kernel=f"k_count_{kernel_name}", launch_ms=stats.kernel_ms,
+            hbm_algorithmic_gbps=stats.algorithmic_bytes / k_s / 1e9, hbm_peak_gbps=HBM_PEAK_GBPS,
+            hbm_frac=stats.algorithmic_bytes / k_s / 1e9 / HBM_PEAK_GBPS,
+        )
+        base = None
+        if world == 1 and args.cpu_seconds > 0:
+            base = cpu_baseline(links, ref, unk, args.cpu_seconds)
+        line = dict(
+            metric="candidate pairs/s", value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=elapsed / max(args.steps, 1) * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
+            dtype="f64", data="synthetic",
+            config=dict(
+                workload=f"{int(args.n_ref)} ref x {int(args.n_unk)} unk uniform full sky, {args.zbins} z-bins, "
+                         f"{args.patches} patches, 1 scale 1-10 arcmin, DD count of crosscorrelate",
+                n_ref=int(args.n_ref), n_unk=int(args.n_unk), z_bins=args.zbins, patches=args.patches,
+                linked_patch_pairs=int(len(links.get_patch_pairs(ref, unk))), kernel=kernel_name,
+                parallelism=f"patch-pair sharding x{world}",
+            ),
+            candidate_pairs_per_step=cand, evaluated_pairs_per_step=evaluated,
+            kernel_ms_per_step=kernel_ms_step, setup_s=setup_s, roofline=roofline, cpu_baseline=base,
+        )
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,130 @@
+"""Shared helpers for the host-level tests (CPU and GPU variants compare against the same golden files)."""
+import numpy as np
+
+from conftest import load_golden
+from oracle import oracle
+
+RTOL_W = 1e-10
+
+
+def oracle_count_fine(layout1, layout2, jobs, thresholds, *, kernel=None):
+    """Stand-in for yet_another_wizz_amd.engine.count_fine built on the CPU oracle: lets the CPU
+    suite exercise the host driver (linkage, thresholds, recombination, sharding) without a GPU."""
+    from yet_another_wizz_amd._lib import CountStats
+
+    def as_cat(layout):
+        return dict(x=layout.x, y=layout.y, z=layout.z, w=layout.w, nb=layout.num_bins, off=layout.offsets)
+
+    counts, sums = oracle.count_jobs(as_cat(layout1), as_cat(layout2), jobs, thresholds)
+    weighted = layout1.w is not None or layout2.w is not None
+    return (sums if weighted else counts.astype(np.float64)), CountStats(candidate_pairs=0)
+
+
+def full_catalogs(tag):
+    """The four catalogues of tests/golden/full_<tag>_inputs.npz."""
+    import yet_another_wizz_amd as yaw
+
+    inp = load_golden(f"full_{tag}_inputs.npz")
+    centers = yaw.AngularCoordinates(inp["patch_centers"])
+    cats = {}
+    for name in ("ref", "unk", "ref_rand", "unk_rand"):
+        frame = {k.split(".", 1)[1]: inp[k] for k in inp.files if k.startswith(name + ".") and ".meta." not in k}
+        cats[name] = yaw.Catalog.from_dataframe(
+            None, frame, ra_name="ra", dec_name="dec", weight_name="w" if "w" in frame else None,
+            redshift_name="z" if "z" in frame else None, patch_centers=centers,
+        )
+    return inp, cats
+
+
+def full_config(inp, cfg, closed):
+    import yet_another_wizz_amd as yaw
+
+    if cfg == "s2":
+        kw = dict(rmin=[2.0, 5.0], rmax=[20.0, 40.0], unit="arcmin")
+    else:
+        kw = dict(rmin=[2.0], rmax=[30.0], unit="arcmin", rweight=-0.8, resolution=12)
+    return yaw.Configuration.create(edges=inp["zedges"], closed=closed, **kw)
+
+
+def check_corrfuncs(prefix, cfs, exp, *, exact):
+    """Compare a list of CorrFunc with the arrays the reference produced."""
+    for s, cf in enumerate(cfs):
+        for kind in ("dd", "dr", "rd", "rr"):
+            key = f"{prefix}.s{s}.{kind}.counts"
+            nc = getattr(cf, kind)
+            if key not in exp.files:
+                assert nc is None, key
+                continue
+            if exact(kind):
+                assert np.array_equal(nc.counts.counts, exp[key]), key  # bit-identical
+            else:
+                np.testing.assert_allclose(nc.counts.counts, exp[key], rtol=RTOL_W, atol=0, err_msg=key)
+            np.testing.assert_allclose(nc.sum_weights.sum_weights1, exp[f"{prefix}.s{s}.{kind}.sum_weights1"], rtol=1e-13)
+            np.testing.assert_allclose(nc.sum_weights.sum_weights2, exp[f"{prefix}.s{s}.{kind}.sum_weights2"], rtol=1e-13)
+            sp = nc.sample_patch_sum()
+            np.testing.assert_allclose(sp.data, exp[f"{prefix}.s{s}.{kind}.sample_data"], rtol=1e-10)
+            np.testing.assert_allclose(sp.samples, exp[f"{prefix}.s{s}.{kind}.sample_samples"], rtol=1e-10)
+        cd = cf.sample()
+        np.testing.assert_allclose(cd.data, exp[f"{prefix}.s{s}.corr_data"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(cd.samples, exp[f"{prefix}.s{s}.corr_samples"], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(cd.error, exp[f"{prefix}.s{s}.corr_error"], rtol=1e-7, atol=1e-12)
+        np.testing.assert_allclose(cd.covariance, exp[f"{prefix}.s{s}.corr_covariance"], rtol=1e-7, atol=1e-14)
+
+
+def run_full_case(tag, cfg, closed):
+    """crosscorrelate + autocorrelate on the golden inputs, checked against the reference's outputs."""
+    import yet_another_wizz_amd as yaw
+
+    inp, cats = full_catalogs(tag)
+    exp = load_golden(f"full_{tag}_{cfg}_{closed}.npz")
+    config = full_config(inp, cfg, closed)
+    # patch metadata feeds the linkage
+    for name, cat in cats.items():
+        np.testing.assert_allclose(cat.get_centers().data, inp[f"{name}.meta.centers"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(cat.get_radii().data, inp[f"{name}.meta.radii"], rtol=1e-9)
+        assert np.array_equal(np.array(cat.get_num_records()), inp[f"{name}.meta.num_records"])
+        np.testing.assert_allclose(np.array(cat.get_sum_weights()), inp[f"{name}.meta.sum_weights"], rtol=1e-13)
+    links = yaw.PatchLinkage.from_catalogs(config, cats["ref"], cats["unk"], cats["ref_rand"], cats["unk_rand"])
+    assert np.array_equal(np.array(sorted(links.iter_patch_id_pairs(auto=False))), exp["cross.job_pairs"])
+    assert np.array_equal(np.array(sorted(links.iter_patch_id_pairs(auto=True))), exp["auto.job_pairs"])
+    plain = cfg != "rw"
+    weighted = {"ref": tag == "w", "unk": tag == "w", "ref_rand": False, "unk_rand": tag == "w"}
+    cross_sides = dict(dd=("ref", "unk"), dr=("ref", "unk_rand"), rd=("ref_rand", "unk"), rr=("ref_rand", "unk_rand"))
+    auto_sides = dict(dd=("ref", "ref"), dr=("ref", "ref_rand"), rr=("ref_rand", "ref_rand"))
+    cfs = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
+    check_corrfuncs("cross", cfs, exp, exact=lambda k: plain and not any(weighted[c] for c in cross_sides[k]))
+    cfs = yaw.autocorrelate(config, cats["ref"], cats["ref_rand"], count_rr=True)
+    check_corrfuncs("auto", cfs, exp, exact=lambda k: plain and not any(weighted[c] for c in auto_sides[k]))
+    for cat in cats.values():
+        cat.drop_layouts()
+
+
+def twodflens_catalogs():
+    import yet_another_wizz_amd as yaw
+
+    g = load_golden("twodflens.npz")
+    kw = dict(ra_name="RA", dec_name="Dec", weight_name="wei", patch_name="patch")
+    data = {c: g[f"data.{c}"] for c in ("RA", "Dec", "redshift", "wei", "patch")}
+    rand = {c: g[f"rand.{c}"] for c in ("RA", "Dec", "redshift", "wei", "patch")}
+    cats = dict(
+        data=yaw.Catalog.from_dataframe(None, data, redshift_name="redshift", **kw),
+        rand=yaw.Catalog.from_dataframe(None, rand, redshift_name="redshift", **kw),
+        unk=yaw.Catalog.from_dataframe(None, data, **kw),
+    )
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.15, zmax=0.7, num_bins=11)
+    return g, cats, config
+
+
+def run_twodflens_case():
+    import yet_another_wizz_amd as yaw
+
+    g, cats, config = twodflens_catalogs()
+    assert np.array_equal(np.asarray(config.binning.binning.edges), g["zedges"])
+    np.testing.assert_allclose(cats["data"].get_centers().data, g["data.meta.centers"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(cats["data"].get_radii().data, g["data.meta.radii"], rtol=1e-9)
+    cfs = yaw.crosscorrelate(config, cats["data"], cats["unk"], ref_rand=cats["rand"])
+    check_corrfuncs("cross", cfs, g, exact=lambda k: False)
+    cfs = yaw.autocorrelate(config, cats["data"], cats["rand"], count_rr=True)
+    check_corrfuncs("auto", cfs, g, exact=lambda k: False)
+    for cat in cats.values():
+        cat.drop_layouts()

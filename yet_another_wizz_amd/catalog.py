@@ -1,0 +1,407 @@
+"""In-memory catalogue split into spatial patches.
+
+Keeps the ``yaw.Catalog`` call shapes (src/yaw/catalog/catalog.py:911-1468): a ``Mapping`` from
+patch id (0..P-1) to :class:`Patch`, the ``from_dataframe`` / ``from_file`` keyword names, and the
+per-patch accessors ``get_centers`` / ``get_radii`` / ``get_num_records`` / ``get_sum_weights`` the
+measurement driver reads.  What is different by design: the reference caches every patch on disk
+(``data.bin`` AoS rows, catalog.py:325-331, patch.py:164-178) and re-reads pickled KD-trees per job;
+here a catalogue is a set of float64 columns held once, sorted by patch, and ``build_trees``
+prepares the (patch, redshift-bin)-sorted SoA layout that is uploaded to HBM once per measurement.
+"""
+from __future__ import annotations
+
+from collections.abc import Mapping
+from pathlib import Path
+
+import numpy as np
+
+from .binning import Binning
+from .coordinates import AngularCoordinates, AngularDistances, radec_to_xyz
+from .options import Closed
+
+__all__ = ["Catalog", "Patch", "Metadata", "InconsistentPatchesError", "PatchLayout"]
+
+PATCH_ID_MAX = np.iinfo(np.int16).max  # the reference stores patch ids as 16-bit integers (datachunk.py:40-42)
+
+
+class InconsistentPatchesError(Exception):
+    """Patches of two catalogues do not line up (catalog.py:80-82)."""
+
+
+def _check_patch_count(num: int) -> None:
+    if num < 1 or num > PATCH_ID_MAX:
+        raise ValueError(f"number of patches must be in range [1, {PATCH_ID_MAX}]")
+
+
+def nearest_center(xyz, centers_xyz, chunk: int = 1 << 18):
+    """Index of the nearest centre in Euclidean xyz for every object.
+
+    Same rule as ``assign_patch_centers`` (catalog.py:229-249, scipy.cluster.vq.vq): squared
+    distance accumulated x, y, z in that order, first minimum wins."""
+    try:
+        from scipy.cluster.vq import vq
+
+        ids, _ = vq(xyz, centers_xyz)
+        return ids.astype(np.int64)
+    except ImportError:  # pragma: no cover - scipy is present in the supported images
+        out = np.empty(len(xyz), dtype=np.int64)
+        for lo in range(0, len(xyz), chunk):
+            blk = xyz[lo : lo + chunk]
+            d = (blk[:, None, 0] - centers_xyz[None, :, 0]) ** 2
+            d += (blk[:, None, 1] - centers_xyz[None, :, 1]) ** 2
+            d += (blk[:, None, 2] - centers_xyz[None, :, 2]) ** 2
+            out[lo : lo + chunk] = d.argmin(axis=1)
+        return out
+
+
+def kmeans_centers(xyz, weights, num: int, *, seed: int = 12345, iterations: int = 25) -> AngularCoordinates:
+    """Patch centres from spherical k-means on a probe sample (stands in for the treecorr k-means of
+    ``create_patch_centers``, catalog.py:183-226; deterministic for a given input)."""
+    rng = np.random.default_rng(seed)
+    n = len(xyz)
+    first = int(rng.integers(n))
+    centers = [xyz[first]]
+    d2 = ((xyz - centers[0]) ** 2).sum(axis=1)
+    for _ in range(1, num):  # k-means++ seeding
+        prob = d2 / d2.sum()
+        centers.append(xyz[int(rng.choice(n, p=prob))])
+        d2 = np.minimum(d2, ((xyz - centers[-1]) ** 2).sum(axis=1))
+    centers = np.array(centers)
+    w = np.ones(n) if weights is None else np.asarray(weights, dtype=np.float64)
+    for _ in range(iterations):
+        ids = nearest_center(xyz, centers)
+        sums = np.zeros_like(centers)
+        for axis in range(3):
+            sums[:, axis] = np.bincount(ids, weights=w * xyz[:, axis], minlength=num)
+        norm = np.linalg.norm(sums, axis=1)
+        moved = np.where(norm[:, None] > 0, sums / np.maximum(norm, 1e-300)[:, None], centers)
+        if np.allclose(moved, centers, atol=1e-12):
+            break
+        centers = moved
+    return AngularCoordinates.from_3d(centers)
+
+
+class Metadata:
+    """Patch summary used to link patches (mirror of patch.py:44-161)."""
+
+    __slots__ = ("num_records", "sum_weights", "center", "radius")
+
+    def __init__(self, *, num_records: int, sum_weights: float, center: AngularCoordinates,
+                 radius: AngularDistances) -> None:
+        self.num_records = num_records
+        self.sum_weights = sum_weights
+        self.center = center
+        self.radius = radius
+
+    def __repr__(self) -> str:
+        return (f"Metadata(num_records={self.num_records}, sum_weights={self.sum_weights}, "
+                f"center={self.center.data[0]}, radius={self.radius.data[0]})")
+
+    @classmethod
+    def compute(cls, coords: AngularCoordinates, *, weights=None, center: AngularCoordinates | None = None):
+        """Sum of weights (or N), weighted mean direction, radius = largest separation from the
+        centre (patch.py:103-147)."""
+        if center is not None and len(center) != 1:
+            raise ValueError("'center' must be one single coordinate")
+        sum_weights = float(len(coords)) if weights is None else float(np.sum(weights))
+        centre = center.copy() if center is not None else coords.mean(weights)
+        return cls(num_records=len(coords), sum_weights=sum_weights, center=centre,
+                   radius=coords.distance(centre).max())
+
+    def to_dict(self) -> dict:
+        return dict(num_records=int(self.num_records), sum_weights=float(self.sum_weights),
+                    center=self.center.tolist()[0], radius=self.radius.tolist()[0])
+
+
+class Patch:
+    """One spatial patch: a contiguous row range of its catalogue's columns."""
+
+    __slots__ = ("meta", "_cat", "_lo", "_hi")
+
+    def __init__(self, catalog: "Catalog", lo: int, hi: int, meta: Metadata) -> None:
+        self._cat, self._lo, self._hi, self.meta = catalog, lo, hi, meta
+
+    def __repr__(self) -> str:
+        return (f"Patch(num_records={self.meta.num_records}, weights={self.has_weights}, "
+                f"redshifts={self.has_redshifts})")
+
+    def __len__(self) -> int:
+        return self._hi - self._lo
+
+    @property
+    def has_weights(self) -> bool:
+        return self._cat._w is not None
+
+    @property
+    def has_redshifts(self) -> bool:
+        return self._cat._z is not None
+
+    @property
+    def coords(self) -> AngularCoordinates:
+        sl = slice(self._lo, self._hi)
+        return AngularCoordinates(np.column_stack([self._cat._ra[sl], self._cat._dec[sl]]))
+
+    @property
+    def weights(self):
+        return None if self._cat._w is None else self._cat._w[self._lo : self._hi]
+
+    @property
+    def redshifts(self):
+        return None if self._cat._z is None else self._cat._z[self._lo : self._hi]
+
+
+class PatchLayout:
+    """Device-ready layout of one catalogue for one redshift binning: float64 SoA columns sorted
+    by (patch, bin), CSR offsets over the P*B segments, and the per-segment sum of weights.
+
+    This is the counterpart of ``build_trees`` (src/yaw/catalog/trees.py:365-429): objects outside
+    the binning are dropped (:414), an unbinned catalogue has one segment per patch (:400-404)."""
+
+    __slots__ = ("x", "y", "z", "w", "offsets", "num_patches", "num_bins", "sum_weights", "device")
+
+    def __init__(self, x, y, z, w, offsets, num_patches: int, num_bins: int) -> None:
+        self.x, self.y, self.z, self.w = x, y, z, w
+        self.offsets = offsets
+        self.num_patches, self.num_bins = num_patches, num_bins
+        if w is None:
+            seg = np.diff(offsets).astype(np.float64)  # sum_weights = float(N) without weights (trees.py:225-227)
+        else:  # ndarray.sum() per tree (trees.py:233-234); an empty tree has 0.0 (trees.py:249-258)
+            seg = np.array([float(w[lo:hi].sum()) for lo, hi in zip(offsets[:-1], offsets[1:])], dtype=np.float64)
+        self.sum_weights = seg.reshape(num_patches, num_bins).T.copy()  # [B_or_1, P]
+        self.device = {}  # Context id -> DeviceCatalog
+
+    @property
+    def weighted(self) -> bool:
+        return self.w is not None
+
+    @property
+    def num_records(self) -> int:
+        return len(self.x)
+
+    def segment_sizes(self):
+        """int64[P, B_or_1]."""
+        return np.diff(self.offsets).reshape(self.num_patches, self.num_bins)
+
+    def sum_weights_for(self, num_bins: int):
+        """f64[B, P]; an unbinned catalogue repeats its single tree for every bin (trees.py:600-601)."""
+        if self.num_bins == 1 and num_bins != 1:
+            return np.repeat(self.sum_weights, num_bins, axis=0)
+        return self.sum_weights
+
+
+class Catalog(Mapping):
+    """Catalogue of points on the sphere, split into P spatial patches with ids 0..P-1."""
+
+    def __init__(self, ra, dec, *, patch_ids, num_patches: int | None = None, weights=None, redshifts=None,
+                 patch_centers: AngularCoordinates | None = None, cache_directory=None) -> None:
+        """Low-level constructor; coordinates in radian. Prefer the ``from_*`` constructors."""
+        ra = np.asarray_chkfinite(ra, dtype=np.float64)
+        dec = np.asarray_chkfinite(dec, dtype=np.float64)
+        patch_ids = np.asarray(patch_ids)
+        if not (len(ra) == len(dec) == len(patch_ids)):
+            raise ValueError("input columns differ in length")
+        if len(ra) == 0:
+            raise ValueError("catalogue is empty")
+        if patch_ids.min() < 0 or patch_ids.max() > PATCH_ID_MAX:
+            raise ValueError(f"'patch_ids' must be in range [0, {PATCH_ID_MAX}]")
+        patch_ids = patch_ids.astype(np.int64)
+        num = int(patch_ids.max()) + 1 if num_patches is None else int(num_patches)
+        _check_patch_count(num)
+        if patch_ids.max() >= num:
+            raise ValueError("patch id exceeds the number of patches")
+        sizes = np.bincount(patch_ids, minlength=num)
+        if np.any(sizes == 0):  # same restriction as the reference (catalog.py:944-947)
+            empty = np.flatnonzero(sizes == 0).tolist()
+            raise ValueError(f"empty patches are not supported (patch ids {empty})")
+        order = np.argsort(patch_ids, kind="stable")
+        self._ra, self._dec = ra[order], dec[order]
+        self._w = None if weights is None else np.asarray_chkfinite(weights, dtype=np.float64)[order]
+        self._z = None if redshifts is None else np.asarray_chkfinite(redshifts, dtype=np.float64)[order]
+        self._patch_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self._xyz = None
+        self._layouts: dict = {}
+        self._active_layout = None
+        self.cache_directory = None if cache_directory is None else Path(cache_directory)
+        if patch_centers is not None and len(patch_centers) != num:
+            raise ValueError("number of patch centers does not match the number of patches")
+        self._patches = {}
+        for pid in range(num):
+            lo, hi = int(self._patch_off[pid]), int(self._patch_off[pid + 1])
+            coords = AngularCoordinates(np.column_stack([self._ra[lo:hi], self._dec[lo:hi]]))
+            meta = Metadata.compute(
+                coords,
+                weights=None if self._w is None else self._w[lo:hi],
+                center=None if patch_centers is None else patch_centers[pid],
+            )
+            self._patches[pid] = Patch(self, lo, hi, meta)
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_arrays(cls, ra, dec, *, weights=None, redshifts=None, patch_centers=None, patch_ids=None,
+                    patch_num: int | None = None, degrees: bool = True, cache_directory=None, probe_size: int = -1):
+        """Build from plain arrays. One of ``patch_centers`` (nearest-centre assignment),
+        ``patch_ids`` (pre-assigned, contiguous from 0) or ``patch_num`` (k-means) is required, with
+        that precedence (``PatchMode.determine``, catalog.py:95-167)."""
+        ra = np.asarray_chkfinite(ra, dtype=np.float64)
+        dec = np.asarray_chkfinite(dec, dtype=np.float64)
+        if degrees:  # datachunk.py:265-267
+            ra, dec = np.deg2rad(ra), np.deg2rad(dec)
+        centers = None
+        if patch_centers is not None:
+            if isinstance(patch_centers, Catalog):
+                centers = patch_centers.get_centers()
+            elif isinstance(patch_centers, AngularCoordinates):
+                centers = patch_centers
+            else:
+                raise TypeError("'patch_centers' must be a set of coordinates or another catalog")
+            _check_patch_count(len(centers))
+        elif patch_ids is None:
+            if patch_num is None:
+                raise ValueError("no patch method specified")
+            if not isinstance(patch_num, (int, np.integer)):
+                raise TypeError("'patch_num' must be an integer")
+            _check_patch_count(int(patch_num))
+            if probe_size < 10 * patch_num:
+                probe_size = int(100_000 * np.sqrt(patch_num))
+            step = max(1, len(ra) // probe_size)
+            x, y, z = radec_to_xyz(ra[::step], dec[::step])
+            centers = kmeans_centers(np.column_stack([x, y, z]), None if weights is None else np.asarray(weights)[::step],
+                                     int(patch_num))
+        num = None
+        if centers is not None:
+            x, y, z = radec_to_xyz(ra, dec)
+            patch_ids = nearest_center(np.column_stack([x, y, z]), centers.to_3d())
+            num = len(centers)
+        return cls(ra, dec, patch_ids=patch_ids, num_patches=num, weights=weights, redshifts=redshifts,
+                   patch_centers=centers, cache_directory=cache_directory)
+
+    @classmethod
+    def from_dataframe(cls, cache_directory, dataframe, *, ra_name: str, dec_name: str, weight_name: str | None = None,
+                       redshift_name: str | None = None, patch_centers=None, patch_name: str | None = None,
+                       patch_num: int | None = None, kappa_name: str | None = None, degrees: bool = True,
+                       overwrite: bool = False, progress: bool = False, max_workers: int | None = None,
+                       chunksize: int | None = None, probe_size: int = -1, **reader_kwargs):
+        """Same signature as ``yaw.Catalog.from_dataframe`` (catalog.py:980-1108). ``dataframe`` may
+        be a pandas DataFrame or any mapping from column name to array. ``cache_directory`` is kept
+        for call compatibility only (nothing is written: the catalogue lives in memory and in HBM);
+        ``kappa_name`` (scalar-field correlations) is outside the nn pair-count path."""
+        if kappa_name is not None:
+            raise NotImplementedError("scalar field ('kappa') correlations are not part of the nn pair-count path")
+        if patch_name is not None and not isinstance(patch_name, str):
+            raise TypeError("'patch_name' must be a string")
+
+        def column(name):
+            return None if name is None else np.asarray(dataframe[name])
+
+        use_ids = patch_centers is None and patch_name is not None
+        return cls.from_arrays(
+            column(ra_name), column(dec_name), weights=column(weight_name), redshifts=column(redshift_name),
+            patch_centers=patch_centers, patch_ids=column(patch_name) if use_ids else None, patch_num=patch_num,
+            degrees=degrees, cache_directory=cache_directory, probe_size=probe_size,
+        )
+
+    @classmethod
+    def from_file(cls, cache_directory, path, *, ra_name: str, dec_name: str, weight_name: str | None = None,
+                  redshift_name: str | None = None, patch_centers=None, patch_name: str | None = None,
+                  patch_num: int | None = None, kappa_name: str | None = None, degrees: bool = True, **kwargs):
+        """Parquet (``.pqt/.parquet``) or ``.npz`` input (reference: catalog.py:1111-1243; FITS and
+        HDF5 readers need libraries that are outside this build's scope)."""
+        path = Path(path)
+        names = [n for n in (ra_name, dec_name, weight_name, redshift_name, patch_name) if n is not None]
+        if path.suffix.lower() in (".pqt", ".parquet"):
+            import pyarrow.parquet as pq
+
+            table = pq.read_table(str(path), columns=names)
+            frame = {n: table[n].to_numpy() for n in names}
+        elif path.suffix.lower() == ".npz":
+            with np.load(str(path)) as data:
+                frame = {n: data[n] for n in names}
+        else:
+            raise ValueError(f"unsupported file type '{path.suffix}' (supported: .pqt, .parquet, .npz)")
+        return cls.from_dataframe(cache_directory, frame, ra_name=ra_name, dec_name=dec_name, weight_name=weight_name,
+                                  redshift_name=redshift_name, patch_centers=patch_centers, patch_name=patch_name,
+                                  patch_num=patch_num, kappa_name=kappa_name, degrees=degrees, **kwargs)
+
+    # ------------------------------------------------------------------ mapping interface
+    def __len__(self) -> int:
+        return len(self._patches)
+
+    def __getitem__(self, patch_id: int) -> Patch:
+        return self._patches[patch_id]
+
+    def __iter__(self):
+        yield from sorted(self._patches)
+
+    def __repr__(self) -> str:
+        return (f"Catalog(num_patches={self.num_patches}, num_records={len(self._ra)}, "
+                f"weights={self.has_weights}, redshifts={self.has_redshifts})")
+
+    @property
+    def num_patches(self) -> int:
+        return len(self)
+
+    @property
+    def has_weights(self) -> bool:
+        return self._w is not None
+
+    @property
+    def has_redshifts(self) -> bool:
+        return self._z is not None
+
+    def get_num_records(self) -> tuple:
+        return tuple(p.meta.num_records for p in self.values())
+
+    def get_sum_weights(self) -> tuple:
+        return tuple(p.meta.sum_weights for p in self.values())
+
+    def get_centers(self) -> AngularCoordinates:
+        return AngularCoordinates.from_coords(p.meta.center for p in self.values())
+
+    def get_radii(self) -> AngularDistances:
+        return AngularDistances.from_dists(p.meta.radius for p in self.values())
+
+    # ------------------------------------------------------------------ device layout
+    def _unit_vectors(self):
+        if self._xyz is None:
+            self._xyz = radec_to_xyz(self._ra, self._dec)  # the exact host values the predicate runs on
+        return self._xyz
+
+    def build_trees(self, binning=None, *, closed=Closed.right, leafsize: int = 16, force: bool = False,
+                    progress: bool = False, max_workers: int | None = None) -> PatchLayout:
+        """Prepare (and cache) the (patch, bin)-sorted layout for ``binning`` (array of edges or
+        ``None``).  Keeps the name and arguments of ``yaw.Catalog.build_trees`` (catalog.py:1406-1461);
+        no tree is built -- ``leafsize`` is accepted and ignored."""
+        bins = None if binning is None else (binning if isinstance(binning, Binning) else Binning(binning, closed=closed))
+        if bins is not None and not self.has_redshifts:
+            raise ValueError("patch has no 'redshifts' attached")  # trees.py:396-397
+        key = None if bins is None else (bins.edges.tobytes(), str(bins.closed))
+        if not force and key in self._layouts:
+            self._active_layout = self._layouts[key]
+            return self._active_layout
+        x, y, z = self._unit_vectors()
+        num_patches = self.num_patches
+        if bins is None:
+            layout = PatchLayout(x, y, z, self._w, self._patch_off.copy(), num_patches, 1)
+        else:
+            num_bins = len(bins)
+            bin_idx = bins.assign(self._z)
+            keep = np.flatnonzero(bin_idx >= 0)
+            patch_of = np.repeat(np.arange(num_patches), np.diff(self._patch_off))
+            seg_key = patch_of[keep] * num_bins + bin_idx[keep]
+            order = keep[np.argsort(seg_key, kind="stable")]
+            offsets = np.zeros(num_patches * num_bins + 1, dtype=np.int64)
+            np.cumsum(np.bincount(seg_key, minlength=num_patches * num_bins), out=offsets[1:])
+            layout = PatchLayout(x[order], y[order], z[order], None if self._w is None else self._w[order], offsets,
+                                 num_patches, num_bins)
+        self._layouts[key] = layout
+        self._active_layout = layout  # what the next count_pairs() uses, like the cached trees.pkl
+        return layout
+
+    def drop_layouts(self) -> None:
+        """Release cached layouts (and with them the device copies)."""
+        for layout in self._layouts.values():
+            for dev in layout.device.values():
+                dev.free()
+            layout.device.clear()
+        self._layouts.clear()
+        self._active_layout = None

@@ -1,0 +1,264 @@
+"""Cross- and autocorrelation drivers on the MI355X pair-count engine.
+
+Drop-in for the nn path of ``yaw.correlation.measurements`` (src/yaw/correlation/measurements.py):
+``crosscorrelate`` (:529-628), ``autocorrelate`` (:455-525), ``PatchLinkage`` (:171-392) keep their
+call shapes, error behaviour and result types.  What changes is the execution model: the
+reference farms one Python task per patch pair to a process pool, each task unpickles KD-trees
+and loops over redshift bins (:88-128, :344-364); here the whole job list of one pair count goes
+to the GPU in a single ``yawhip_count_pairs`` call against catalogues resident in HBM, the jobs
+are sharded over the processes of a ``torch.distributed`` group (one per GPU) and the dense
+``[B, E-1, P, P]`` tensor is combined with one all-reduce.
+"""
+from __future__ import annotations
+
+import logging
+from itertools import compress
+
+import numpy as np
+
+from . import engine, parallel
+from .angular_bins import plan_for_limits
+from .catalog import Catalog, InconsistentPatchesError
+from .coordinates import AngularDistances
+from .corrfunc import CorrFunc
+from .paircounts import NormalisedCounts, PatchedCounts, PatchedSumWeights
+
+__all__ = ["autocorrelate", "crosscorrelate", "PatchLinkage", "get_max_angle", "check_patch_conistency"]
+
+logger = logging.getLogger("yet_another_wizz_amd")
+
+
+def _log_info(*args) -> None:
+    if parallel.world()[0] == 0:
+        logger.info(*args)
+
+
+def check_patch_conistency(catalog: Catalog, *catalogs: Catalog, rtol: float = 0.5) -> None:
+    """Patch centres of the other catalogues must lie within ``rtol`` patch radii of
+    ``catalog``'s centres (measurements.py:131-149; the reference's spelling is kept)."""
+    centers, radii = catalog.get_centers(), catalog.get_radii()
+    for other in catalogs:
+        offset = centers.distance(other.get_centers())
+        if np.any(offset.data / radii.data > rtol):
+            raise InconsistentPatchesError("patch centers are not aligned")
+
+
+def get_max_angle(config, redshift_limit: float = 0.05) -> AngularDistances:
+    """Largest separation any pair can contribute at: the upper scale limits evaluated at
+    max(zmin, redshift_limit) (measurements.py:152-168)."""
+    z = max(config.binning.zmin, redshift_limit)
+    _, ang_max = config.scales.scales.get_angle_radian(z, cosmology=config.cosmology)
+    return AngularDistances(np.max(ang_max))
+
+
+def angular_plans(config):
+    """One :class:`AngularBinPlan` per redshift bin: scale limits at the bin centre
+    (measurements.py:99,110-112) -> edges -> thresholds."""
+    scales, cosmology = config.scales.scales, config.cosmology
+    return [
+        plan_for_limits(*scales.get_angle_radian(zmid, cosmology=cosmology), config.scales.rweight,
+                        config.scales.resolution)
+        for zmid in config.binning.binning.mids
+    ]
+
+
+def threshold_table(plans) -> np.ndarray:
+    """f64[B, Emax]. Bins with fewer edges are padded by repeating their last threshold: the
+    padded fine bins (t < s <= t) are empty by construction."""
+    n_edges = max(p.num_edges for p in plans)
+    table = np.empty((len(plans), n_edges), dtype=np.float64)
+    for k, plan in enumerate(plans):
+        table[k, : plan.num_edges] = plan.thresholds
+        table[k, plan.num_edges :] = plan.thresholds[-1]
+    return table
+
+
+class PatchLinkage:
+    """Which patch pairs can contain pairs of objects within the largest scale.
+
+    Patches i, j are linked if their centres are closer than r_i + r_j + theta_max
+    (measurements.py:193-237); every pair count of one measurement shares the linkage."""
+
+    def __init__(self, config, patch_links: dict) -> None:
+        self.config = config
+        self.patch_links = patch_links
+
+    @classmethod
+    def from_catalogs(cls, config, catalog: Catalog, *catalogs: Catalog):
+        if any(set(cat.keys()) != set(catalog.keys()) for cat in catalogs):
+            raise InconsistentPatchesError("patch IDs do not match")
+        max_angle = get_max_angle(config).data[0]
+        # the catalogue with the most records constrains centres / radii best (measurements.py:220-225)
+        ranked = sorted([catalog, *catalogs], key=lambda cat: cat.get_num_records(), reverse=True)
+        ref_cat, others = ranked[0], ranked[1:]
+        check_patch_conistency(ref_cat, *others)
+        patch_ids = list(ref_cat.keys())
+        centers, radii = ref_cat.get_centers(), ref_cat.get_radii().data
+        links = {}
+        for pid, center, radius in zip(patch_ids, centers, radii):
+            linked = centers.distance(center).data < (radii + radius + max_angle)
+            links[pid] = set(compress(patch_ids, linked))
+        return cls(config, links)
+
+    @property
+    def num_total(self) -> int:
+        return len(self.patch_links) ** 2
+
+    @property
+    def num_links(self) -> int:
+        return sum(len(v) for v in self.patch_links.values())
+
+    @property
+    def density(self) -> float:
+        return self.num_links / self.num_total
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}(num_links={self.num_links}, density={self.density:.0%})"
+
+    def iter_patch_id_pairs(self, *, auto: bool):
+        """All linked (i, j): every ordered pair for a cross count, i <= j for an auto count
+        (measurements.py:258-289). Same set as the reference; the order (diagonal jobs first, then
+        by patch id) only matters for scheduling, which happens in ``partition_jobs``."""
+        for i in sorted(self.patch_links):
+            if i in self.patch_links[i]:
+                yield (i, i)
+        for i in sorted(self.patch_links):
+            for j in sorted(self.patch_links[i]):
+                if j != i and (not auto or j > i):
+                    yield (i, j)
+
+    def get_patch_pairs(self, catalog1: Catalog, catalog2: Catalog | None = None) -> np.ndarray:
+        """int32[n_jobs, 2] job table (stands in for the tuple of ``PatchPair`` objects,
+        measurements.py:291-305)."""
+        pairs = list(self.iter_patch_id_pairs(auto=catalog2 is None))
+        return np.array(pairs, dtype=np.int32).reshape(-1, 2)
+
+    # ------------------------------------------------------------------ the hot path
+    def count_pairs(self, main_catalog: Catalog, *optional_catalog: Catalog, progress: bool = False,
+                    max_workers: int | None = None, mode: str = "nn", count_type_info: str | None = None):
+        """Pair counts between the patches of one (auto) or two catalogues -> one
+        ``NormalisedCounts`` per scale (measurements.py:307-367)."""
+        if str(mode) != "nn":
+            raise NotImplementedError("only the 'nn' counting mode is part of this build")
+        if len(optional_catalog) > 1:
+            raise TypeError("count_pairs() takes at most two catalogues")
+        if count_type_info is not None:
+            _log_info("counting %s from patch pairs", count_type_info)
+        auto = len(optional_catalog) == 0
+        cat2 = main_catalog if auto else optional_catalog[0]
+        binning = self.config.binning.binning
+        num_bins, num_patches = len(binning), len(main_catalog)
+        layout1, layout2 = _active_layout(main_catalog, num_bins), _active_layout(cat2, num_bins)
+
+        jobs = self.get_patch_pairs(main_catalog, None if auto else cat2)
+        plans = angular_plans(self.config)
+        thresholds = threshold_table(plans)
+        num_fine = thresholds.shape[1] - 1
+
+        # shard the independent jobs over the process group (one process per GPU)
+        rank, size = parallel.world()
+        mine = np.arange(len(jobs))
+        if size > 1:
+            sizes1, sizes2 = layout1.segment_sizes(), layout2.segment_sizes()
+            cost = (sizes1[jobs[:, 0]].sum(axis=1, dtype=np.float64)
+                    * sizes2[jobs[:, 1]].sum(axis=1, dtype=np.float64))
+            mine = parallel.partition_jobs(cost, size)[rank]
+        fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds)
+        self.last_stats = stats
+
+        # dense [B, E-1, P, P] tensor; each slot is written by exactly one rank
+        dense = np.zeros((num_bins, num_fine, num_patches, num_patches), dtype=np.float64)
+        if len(mine):
+            dense[:, :, jobs[mine, 0], jobs[mine, 1]] = np.moveaxis(fine, 0, -1)
+        dense = parallel.allreduce_sum(dense)
+
+        # host epilogue, O(jobs * B * E): separation weights, per-scale recombination, halving of
+        # the doubly counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364)
+        scale_counts = [PatchedCounts.zeros(binning, num_patches, auto=auto) for _ in range(self.config.scales.num_scales)]
+        id1, id2 = jobs[:, 0], jobs[:, 1]
+        halve = np.where(id1 == id2, 0.5, 1.0) if auto else None
+        for k, plan in enumerate(plans):
+            per_scale = plan.combine(dense[k, : plan.num_edges - 1][:, id1, id2].T)  # [n_jobs, E-1] -> [n_jobs, S]
+            if halve is not None:
+                per_scale = per_scale * halve[:, np.newaxis]
+            for s, container in enumerate(scale_counts):
+                container.counts[k, id1, id2] = per_scale[:, s]
+
+        sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
+                                        auto=auto)
+        return [NormalisedCounts(counts, sum_weights) for counts in scale_counts]
+
+    def count_pairs_optional(self, main_catalog, *optional_catalog, **kwargs):
+        """``count_pairs`` that yields ``None`` per scale if any catalogue is missing
+        (measurements.py:369-392)."""
+        if any(cat is None for cat in (main_catalog, *optional_catalog)):
+            return [None] * self.config.scales.num_scales
+        return self.count_pairs(main_catalog, *optional_catalog, **kwargs)
+
+
+def _active_layout(catalog: Catalog, num_bins: int):
+    layout = catalog._active_layout
+    if layout is None:  # the reference fails in BinnedTrees.__init__ (trees.py:473-474)
+        raise FileNotFoundError("no trees found for catalog: call build_trees() first")
+    if layout.num_bins not in (1, num_bins):
+        raise ValueError(f"catalog was binned into {layout.num_bins} redshift bins, configuration has {num_bins}")
+    return layout
+
+
+def _require_distinct(*catalogs) -> None:
+    """Counterpart of ``ensure_unique_catalogs`` (measurements.py:432-448): the reference rejects
+    catalogues that share a cache directory; here the state that must not be shared is the active
+    layout of a catalogue object."""
+    present = [cat for cat in catalogs if cat is not None]
+    if len({id(cat) for cat in present}) != len(present):
+        raise ValueError("each catalog must be a separate Catalog instance to avoid interference.")
+
+
+def autocorrelate(config, data: Catalog, random: Catalog, *, count_rr: bool = True, progress: bool = False,
+                  max_workers: int | None = None) -> list:
+    """Angular autocorrelation in redshift slices: DD, DR and (optionally) RR -> ``[CorrFunc]``, one
+    per scale (measurements.py:455-525)."""
+    _require_distinct(data, random)
+    edges, closed = config.binning.edges, config.binning.closed
+    _log_info("building data trees")
+    data.build_trees(edges, closed=closed)
+    _log_info("building random trees")
+    random.build_trees(edges, closed=closed)
+    _log_info("computing auto-correlation from DD, DR" + (", RR" if count_rr else ""))
+    links = PatchLinkage.from_catalogs(config, data, random)
+    kwargs = dict(progress=progress, max_workers=max_workers)
+    DD = links.count_pairs(data, **kwargs, count_type_info="DD")
+    DR = links.count_pairs(data, random, **kwargs, count_type_info="DR")
+    RR = links.count_pairs_optional(random if count_rr else None, **kwargs, count_type_info="RR")
+    return [CorrFunc(dd, dr, None, rr) for dd, dr, rr in zip(DD, DR, RR)]
+
+
+def crosscorrelate(config, reference: Catalog, unknown: Catalog, *, ref_rand: Catalog | None = None,
+                   unk_rand: Catalog | None = None, progress: bool = False, max_workers: int | None = None) -> list:
+    """Angular cross-correlation between redshift slices of ``reference`` and the whole ``unknown``
+    sample: DD always, DR / RD / RR depending on the randoms given -> ``[CorrFunc]``, one per scale
+    (measurements.py:529-628)."""
+    _require_distinct(reference, unknown, ref_rand, unk_rand)
+    count_dr, count_rd = unk_rand is not None, ref_rand is not None
+    if not count_dr and not count_rd:
+        raise ValueError("at least one random dataset must be provided")
+    edges, closed = config.binning.edges, config.binning.closed
+    randoms = []
+    _log_info("building reference data trees")
+    reference.build_trees(edges, closed=closed)
+    if count_rd:
+        ref_rand.build_trees(edges, closed=closed)
+        randoms.append(ref_rand)
+    unknown.build_trees(None)
+    if count_dr:
+        unk_rand.build_trees(None)
+        randoms.append(unk_rand)
+    _log_info("computing cross-correlation from DD" + (", DR" if count_dr else "") + (", RD" if count_rd else "")
+              + (", RR" if count_dr and count_rd else ""))
+    links = PatchLinkage.from_catalogs(config, reference, unknown, *randoms)
+    kwargs = dict(progress=progress, max_workers=max_workers)
+    DD = links.count_pairs(reference, unknown, **kwargs, count_type_info="DD")
+    DR = links.count_pairs_optional(reference, unk_rand, **kwargs, count_type_info="DR")
+    RD = links.count_pairs_optional(ref_rand, unknown, **kwargs, count_type_info="RD")
+    RR = links.count_pairs_optional(ref_rand, unk_rand, **kwargs, count_type_info="RR")
+    return [CorrFunc(dd, dr, rd, rr) for dd, dr, rd, rr in zip(DD, DR, RD, RR)]

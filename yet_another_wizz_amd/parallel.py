@@ -1,0 +1,63 @@
+"""Distribution of patch-pair jobs over GPUs: one process per GPU (``torch.distributed``; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+Replaces the reference's task farm (src/yaw/utils/parallel.py:251-346: multiprocessing pool or
+mpi4py root/worker send-recv).  Jobs are independent and write disjoint ``[.,.,i,j]`` slots of the
+result tensor, so the only exchange step is one sum all-reduce of that tensor at the end; every
+slot is non-zero on exactly one rank, which makes the sum exact and order independent.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+__all__ = ["world", "partition_jobs", "allreduce_sum", "local_device_index"]
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:  # torch missing: single process only
+        return None
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world() -> tuple[int, int]:
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    dist = _dist()
+    return (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
+
+
+def local_device_index() -> int:
+    """GPU of this process: LOCAL_RANK as set by ``python -m torch.distributed.run``."""
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def partition_jobs(costs, num_parts: int) -> list:
+    """Longest-processing-time-first greedy assignment. Returns ``num_parts`` sorted index arrays.
+
+    The reference also schedules the heaviest (diagonal) jobs first (measurements.py:262-273);
+    with a static assignment the same idea becomes LPT over the candidate-pair cost N1*N2."""
+    costs = np.asarray(costs, dtype=np.float64)
+    loads = np.zeros(num_parts)
+    parts = [[] for _ in range(num_parts)]
+    for j in np.argsort(-costs, kind="stable"):
+        dest = int(np.argmin(loads))
+        parts[dest].append(int(j))
+        loads[dest] += costs[j]
+    return [np.array(sorted(p), dtype=np.int64) for p in parts]
+
+
+def allreduce_sum(array: np.ndarray) -> np.ndarray:
+    """Sum ``array`` (int64 or float64) over all ranks; identity for a single process."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return array
+    import torch
+
+    tensor = torch.from_numpy(np.ascontiguousarray(array))
+    if dist.get_backend() == "nccl":
+        tensor = tensor.to(torch.device("cuda", local_device_index()))
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor.cpu().numpy()
