@@ -95,11 +95,11 @@ def cpu_baseline(links, ref, unk, budget_s):
     c1, c2 = as_cat(l1), as_cat(l2)
     sizes1, sizes2 = l1.segment_sizes(), l2.segment_sizes()
     cost = sizes1[jobs[:, 0]].sum(axis=1).astype(np.float64) * sizes2[jobs[:, 1]].sum(axis=1)
-    # calibrate on a thin slice (one z-bin of one job), then size the sample to the budget
+    # calibrate on the first two jobs, then size the sample to the budget
     t0 = time.perf_counter()
-    oracle.count_jobs(c1, c2, jobs[:1], t[:1])
+    oracle.count_jobs(c1, c2, jobs[:2], t)
     calib = time.perf_counter() - t0
-    rate = max(float(sizes1[jobs[0, 0], 0]) * float(sizes2[jobs[0, 1]].sum()) / max(calib, 1e-6), 1.0)
+    rate = max(float(cost[:2].sum()) / max(calib, 1e-6), 1.0)
     n_sample = int(np.clip(np.searchsorted(np.cumsum(cost), rate * budget_s), 1, len(jobs)))
     sample = jobs[:n_sample]
     t0 = time.perf_counter()

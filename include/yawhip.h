@@ -53,7 +53,7 @@ typedef struct yawhip_stats {
     int64_t candidate_pairs;   /* sum over (job, bin) of N1(p,k) * N2(q,k): the brute-force work unit   */
     int64_t evaluated_pairs;   /* pair distances the launched kernels actually evaluated (<= candidates
                                   when tile culling is active, padded lanes not included)               */
-    int64_t algorithmic_bytes; /* compulsory HBM bytes: every object of every (job,bin) segment once     */
+    int64_t algorithmic_bytes; /* compulsory HBM bytes: per job, every object of both patches once       */
     int64_t n_workgroups;      /* workgroups of the dominant (count) kernel                              */
     int32_t n_launches;        /* kernel launches in this call                                           */
     int32_t kernel_used;       /* yawhip_kernel actually run                                             */

@@ -46,8 +46,8 @@ def lib():
             build()
         _LIB = ctypes.CDLL(so)
         _LIB.yaw_oracle_count_tree.restype = None
-        _LIB.yaw_oracle_count_jobs.restype = None
-        _LIB.yaw_oracle_num_threads.restype = ctypes.c_int
+        _LIB.yaw_oracle_count_jobs.restype = ctypes.c_int
+        _LIB.yaw_oracle_max_threads.restype = ctypes.c_int
     return _LIB
 
 
@@ -199,9 +199,10 @@ def angular_tree_count(xyz1, w1, xyz2, w2, ang_min, ang_max, rweight=None, resol
     return finalize(fine, ang_bins, lim, rweight)
 
 
-def count_jobs(cat1, cat2, jobs, t):
+def count_jobs(cat1, cat2, jobs, t, threads=None):
     """Job-level C brute force. cat = dict(x, y, z, w|None, nb, off[int64 P*nb+1]);
-    returns (int64 counts[n_jobs,B,E-1], f64 sums[n_jobs,B,E-1])."""
+    returns (int64 counts[n_jobs,B,E-1], f64 sums[n_jobs,B,E-1]). ``threads`` OpenMP threads
+    (default: num_threads()); the result does not depend on it."""
     t = _c(t)
     n_bins, n_edges = t.shape
     jobs = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2)
@@ -212,17 +213,24 @@ def count_jobs(cat1, cat2, jobs, t):
     b = {k: _c(cat2[k]) for k in ("x", "y", "z", "w")}
     off1 = np.ascontiguousarray(cat1["off"], dtype=np.int64)
     off2 = np.ascontiguousarray(cat2["off"], dtype=np.int64)
-    lib().yaw_oracle_count_jobs(
+    rc = lib().yaw_oracle_count_jobs(
         _d(a["x"]), _d(a["y"]), _d(a["z"]), _d(a["w"]), ctypes.c_int(cat1["nb"]), off1.ctypes.data_as(_ip),
         _d(b["x"]), _d(b["y"]), _d(b["z"]), _d(b["w"]), ctypes.c_int(cat2["nb"]), off2.ctypes.data_as(_ip),
         ctypes.c_int(len(jobs)), jobs.ctypes.data_as(_i32p), ctypes.c_int(n_bins), ctypes.c_int(n_edges),
-        _d(t), counts.ctypes.data_as(_ip), _d(sums),
+        _d(t), ctypes.c_int(threads or num_threads()), counts.ctypes.data_as(_ip), _d(sums),
     )
+    if rc != 0:
+        raise MemoryError("oracle: allocation failed")
     return counts, sums
 
 
 def num_threads() -> int:
-    return int(lib().yaw_oracle_num_threads())
+    """Threads the job-level oracle uses: YAW_ORACLE_THREADS, else min(OpenMP max, 16) -- 16 is the
+    CPU share of a one-GPU box."""
+    env = os.environ.get("YAW_ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, min(int(lib().yaw_oracle_max_threads()), 16))
 
 
 # ----------------------------------------------------------------------------- catalogue level

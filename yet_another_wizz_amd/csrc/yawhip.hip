@@ -506,16 +506,19 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     std::vector<int64_t> prefix((size_t)n_slots + 1);
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
-    for (int j = 0; j < n_jobs; ++j)
+    for (int j = 0; j < n_jobs; ++j) {
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
             prefix[(size_t)j * n_bins + k] = n_items;
             if (n1 > 0 && n2 > 0) {
                 n_items += (n2 + tile - 1) / tile;
                 cand += n1 * n2;
-                abytes += n1 * obj_bytes1 + n2 * obj_bytes2;
             }
         }
+        // algorithmic bytes of a job = every object of the two patches once (Bobj * (N1 + N2))
+        for (int k = 0; k < c1->nb; ++k) abytes += seg_len(c1, jobs[2 * j], k) * obj_bytes1;
+        for (int k = 0; k < c2->nb; ++k) abytes += seg_len(c2, jobs[2 * j + 1], k) * obj_bytes2;
+    }
     prefix[(size_t)n_slots] = n_items;
 
     const bool want_counts = fine_counts != nullptr;
