@@ -32,7 +32,7 @@ def _single(xyz, w):
                 off=np.array([0, len(xyz)], dtype=np.int64))
 
 
-KERNELS = ["exact"]
+KERNELS = ["exact", "filter"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -172,3 +172,54 @@ def test_errors(ctx):
         _lib.count_pairs(ctx, d1, d1, [[0, 0]], np.array([[1e-5, 1e-6]]))
     with pytest.raises(_lib.YawhipError, match="patch id"):
         _lib.count_pairs(ctx, d1, d1, [[0, 7]], np.array([[1e-6, 1e-5]]))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("theta_arcmin", [0.05, 1.0, 10.0, 120.0])
+def test_borderline_pairs(ctx, kernel, theta_arcmin):
+    """Partners placed within 1e-6 ... 1e-16 (relative) of the outer and inner edge: any pre-filter or
+    culling step must be conservative, the exact predicate decides. Bit parity with the oracle."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(int(theta_arcmin * 100))
+    n = 3000
+    ra = rng.uniform(0.0, 2 * np.pi, n)
+    dec = np.arcsin(rng.uniform(-1, 1, n))
+    a = np.column_stack(oracle.to_3d(ra, dec))
+    # a random tangent direction per point
+    v = rng.normal(size=(n, 3))
+    v -= (v * a).sum(1, keepdims=True) * a
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    theta = theta_arcmin * np.pi / 10800
+    lim = oracle.parse_ang_limits([theta * 0.1], [theta])
+    ang_bins = oracle.ang_bins_for(lim, None, None)
+    t = oracle.thresholds_for(ang_bins)[None, :]
+    edge = np.where(rng.random(n) < 0.5, ang_bins[1], ang_bins[0])
+    delta = rng.choice([0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-14, -1e-14, 1e-12, -1e-12, 1e-9, -1e-9, 1e-6, -1e-6], n)
+    ang = edge * (1.0 + delta)
+    b = a * np.cos(ang)[:, None] + v * np.sin(ang)[:, None]
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    c1, c2 = _single(a, None), _single(b, None)
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
+    counts, _, _ = _lib.count_pairs(ctx, d1, d2, [[0, 0]], t, kernel=kernel)
+    assert np.array_equal(counts, exp)
+    assert exp.sum() > n // 4  # the engineered partners dominate the count
+    # swap roles (lane side <-> streamed side)
+    counts, _, _ = _lib.count_pairs(ctx, d2, d1, [[0, 0]], t, kernel=kernel)
+    assert np.array_equal(counts, exp)
+
+
+def test_non_unit_vectors_fall_back_to_exact(ctx):
+    """The FP32 pre-filter presumes unit vectors; other inputs must still be counted exactly."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(11)
+    a = rng.normal(size=(500, 3)) * 0.01 + np.array([0.3, 0.2, 0.1])
+    b = rng.normal(size=(700, 3)) * 0.01 + np.array([0.3, 0.2, 0.1])
+    c1, c2 = _single(a, None), _single(b, None)
+    t = np.array([[1e-5, 1e-4, 4e-4]])
+    exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
+    counts, _, stats = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel="filter")
+    assert np.array_equal(counts, exp) and exp.sum() > 1000
+    assert stats.kernel_used == _lib.KERNEL_EXACT

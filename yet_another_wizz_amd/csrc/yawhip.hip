@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -70,23 +71,43 @@ struct alignas(16) Obj {  // one streamed object in LDS: two 16-byte broadcast r
     double x, y, z, w;
 };
 
+struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte broadcast read
+    float x, y, z, pad;
+};
+
+// Pre-filter guard (see k_count): |dot32 - a.b| <= 5.000001 u for unit vectors rounded to float32 and
+// a mul + 2 fma evaluation (u = 2^-24); 8 u leaves room for |a|^2 deviating from 1 by < 1e-9 and for
+// the rounding of the threshold itself.
+constexpr double FILTER_GUARD = 8.0 * 5.9604644775390625e-8;
+constexpr double UNIT_NORM_TOL = 1e-9;
+
 // ------------------------------------------------------------------------------------------------
-// Exact FP64 brute-force count.
+// Pair count kernel.
 //   R         objects per lane (lane tile = 256*R objects of the c2 segment)
 //   WEIGHTED  accumulate w_a*w_b in float64 (else count in uint32)
 //   PRIVATE   per-lane private LDS histogram (deterministic); else one shared LDS histogram per
 //             workgroup updated with LDS atomics (only used when E is too large for private ones)
+//   FILTER    false: every pair is evaluated in FP64 (8 flop + 1 compare);
+//             true:  every pair is first tested in FP32 as  a.b >= 1 - t_max/2 - guard  (mul + 2 fma
+//                    + compare on the float32 images of the unit vectors); only survivors (a few
+//                    1e-5 of the pairs) are evaluated with the exact FP64 predicate. The test is
+//                    conservative: s = |a|^2 + |b|^2 - 2 a.b, so s <= t_max implies
+//                    a.b >= 1 - t_max/2 - eps_norm, and the float32 dot product is within 5.000001 u
+//                    of a.b; dthr[k] is that bound rounded down. A pair the filter drops therefore has
+//                    s > t_max and belongs to no bin: results are bit-identical to FILTER=false.
 // ------------------------------------------------------------------------------------------------
-template <int R, bool WEIGHTED, bool PRIVATE>
-__global__ __launch_bounds__(WG) void k_count_exact(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
-                                                    const int64_t *__restrict__ prefix, int n_slots, int n_bins,
-                                                    int n_edges, const double *__restrict__ t, int64_t item_base,
-                                                    unsigned long long *__restrict__ out_counts,
-                                                    double *__restrict__ partials) {
+template <int R, bool WEIGHTED, bool PRIVATE, bool FILTER>
+__global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
+                                              const int64_t *__restrict__ prefix, int n_slots, int n_bins,
+                                              int n_edges, const double *__restrict__ t,
+                                              const float *__restrict__ dthr, int64_t item_base,
+                                              unsigned long long *__restrict__ out_counts,
+                                              double *__restrict__ partials) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Obj *stage = reinterpret_cast<Obj *>(lds_raw);                                  // [2][STAGE]
-    double *thr = reinterpret_cast<double *>(lds_raw + 2 * STAGE * sizeof(Obj));    // [n_edges]
+    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw + 2 * STAGE * sizeof(Obj));     // [2][STAGE]
+    double *thr = reinterpret_cast<double *>(lds_raw + 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)));  // [n_edges]
     HistT *hist = reinterpret_cast<HistT *>(thr + ((n_edges + 1) & ~1));            // [nf][WG] or [nf]
 
     const int tid = threadIdx.x;
@@ -118,6 +139,15 @@ __global__ __launch_bounds__(WG) void k_count_exact(CatView c1, CatView c2, cons
         az[r] = ok ? c2.z[i] : PAD_COORD;
         aw[r] = (WEIGHTED && ok && c2.w) ? c2.w[i] : (ok ? 1.0 : 0.0);
     }
+    float fx[R], fy[R], fz[R];  // float32 images; a padded lane gets 0 -> dot = 0 < any threshold >= ~-1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const bool ok = a0 + (int64_t)r * WG + tid < a_seg1;
+        fx[r] = ok ? (float)ax[r] : 0.f;
+        fy[r] = ok ? (float)ay[r] : 0.f;
+        fz[r] = ok ? (float)az[r] : 0.f;
+    }
+    const float dmin = FILTER ? dthr[k] : 0.f;
 
     for (int e = tid; e < n_edges; e += WG) thr[e] = t[(int64_t)k * n_edges + e];
     if (PRIVATE) {
@@ -138,6 +168,7 @@ __global__ __launch_bounds__(WG) void k_count_exact(CatView c1, CatView c2, cons
         o.x = ok ? c1.x[i] : 0.0; o.y = ok ? c1.y[i] : 0.0; o.z = ok ? c1.z[i] : 0.0;
         o.w = (WEIGHTED && ok && c1.w) ? c1.w[i] : 1.0;
         stage[tid] = o;
+        if (FILTER) stagef[tid] = ObjF{(float)o.x, (float)o.y, (float)o.z, 0.f};
     }
     __syncthreads();
 
@@ -155,39 +186,73 @@ __global__ __launch_bounds__(WG) void k_count_exact(CatView c1, CatView c2, cons
         const int64_t left = nb_total - (int64_t)st * STAGE;
         const int n = left < STAGE ? (int)left : STAGE;
 
-        for (int i = 0; i < n; ++i) {
-            const Obj b = cur[i];  // wave-wide broadcast read
-            double s[R];
-            bool any = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const double dx = ax[r] - b.x;
-                const double dy = ay[r] - b.y;
-                const double dz = az[r] - b.z;
-                const double xx = dx * dx;
-                const double yy = dy * dy;
-                const double zz = dz * dz;
-                const double sxy = xx + yy;
-                s[r] = sxy + zz;
-                any |= (s[r] <= tmax);
+        const ObjF *curf = stagef + (st & 1) * STAGE;
+        // exact evaluation + histogram update of lane object r against streamed object b
+        auto settle = [&](int r, const Obj &b) {
+            const double dx = ax[r] - b.x;
+            const double dy = ay[r] - b.y;
+            const double dz = az[r] - b.z;
+            const double xx = dx * dx;
+            const double yy = dy * dy;
+            const double zz = dz * dz;
+            const double sxy = xx + yy;
+            const double s = sxy + zz;
+            if (s <= tmax) {
+                int cnt = 0;
+                for (int e = 0; e < n_edges; ++e) cnt += (s > thr[e]) ? 1 : 0;
+                if (cnt > 0) {  // t[cnt-1] < s <= t[cnt]
+                    const HistT v = WEIGHTED ? HistT(aw[r] * b.w) : HistT(1);
+                    if (PRIVATE) hist[(cnt - 1) * WG + tid] += v;
+                    else atomicAdd(&hist[cnt - 1], v);
+                }
             }
-            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // rare: some lane has a pair inside the outer edge
+        };
+        if (FILTER) {
+            for (int i = 0; i < n; ++i) {
+                const ObjF bf = curf[i];  // wave-wide broadcast read, 16 B
+                float d[R];
+                float best = -2.f;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (s[r] <= tmax) {
-                        int cnt = 0;
-                        for (int e = 0; e < n_edges; ++e) cnt += (s[r] > thr[e]) ? 1 : 0;
-                        if (cnt > 0) {  // t[cnt-1] < s <= t[cnt]
-                            const HistT v = WEIGHTED ? HistT(aw[r] * b.w) : HistT(1);
-                            if (PRIVATE) hist[(cnt - 1) * WG + tid] += v;
-                            else atomicAdd(&hist[cnt - 1], v);
-                        }
-                    }
+                    d[r] = __builtin_fmaf(fz[r], bf.z, __builtin_fmaf(fy[r], bf.y, fx[r] * bf.x));
+                    best = fmaxf(best, d[r]);
+                }
+                if (__builtin_amdgcn_ballot_w64(best >= dmin) != 0ull) {  // rare: a pair may be inside the outer edge
+                    const Obj b = cur[i];
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (d[r] >= dmin) settle(r, b);
+                }
+            }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                const Obj b = cur[i];  // wave-wide broadcast read
+                double s[R];
+                bool any = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double dx = ax[r] - b.x;
+                    const double dy = ay[r] - b.y;
+                    const double dz = az[r] - b.z;
+                    const double xx = dx * dx;
+                    const double yy = dy * dy;
+                    const double zz = dz * dz;
+                    const double sxy = xx + yy;
+                    s[r] = sxy + zz;
+                    any |= (s[r] <= tmax);
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0ull) {  // rare: some lane has a pair inside the outer edge
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        if (s[r] <= tmax) settle(r, b);
                 }
             }
         }
 
-        if (have_next) stage[((st + 1) & 1) * STAGE + tid] = nxt;
+        if (have_next) {
+            stage[((st + 1) & 1) * STAGE + tid] = nxt;
+            if (FILTER) stagef[((st + 1) & 1) * STAGE + tid] = ObjF{(float)nxt.x, (float)nxt.y, (float)nxt.z, 0.f};
+        }
         __syncthreads();
     }
 
@@ -255,6 +320,7 @@ struct yawhip_ctx {
     DevBuf<int32_t> d_jobs;
     DevBuf<int64_t> d_prefix;
     DevBuf<double> d_t;
+    DevBuf<float> d_dthr;
     DevBuf<unsigned long long> d_counts;
     DevBuf<double> d_sums;
     DevBuf<double> d_partials;
@@ -268,16 +334,17 @@ struct yawhip_catalog {
     int64_t *off = nullptr;
     std::vector<int64_t> h_off;
     int64_t device_bytes = 0;
+    bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
 };
 
 namespace {
 
 CatView view_of(const yawhip_catalog *c) { return CatView{c->x, c->y, c->z, c->w, c->off, c->nb}; }
 
-template <int R, bool W, bool P>
-hipError_t launch_exact(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots, int n_bins,
+template <int R, bool W, bool P, bool F>
+hipError_t launch_count(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots, int n_bins,
                         int n_edges, int64_t n_items, size_t lds_bytes) {
-    auto kern = k_count_exact<R, W, P>;
+    auto kern = k_count<R, W, P, F>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -287,22 +354,32 @@ hipError_t launch_exact(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_
     for (int64_t base = 0; base < n_items; base += max_grid) {
         const int64_t g = std::min(max_grid, n_items - base);
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WG), lds_bytes, ctx->stream, view_of(c1), view_of(c2),
-                           ctx->d_jobs.ptr, ctx->d_prefix.ptr, n_slots, n_bins, n_edges, ctx->d_t.ptr, base,
-                           ctx->d_counts.ptr, ctx->d_partials.ptr);
+                           ctx->d_jobs.ptr, ctx->d_prefix.ptr, n_slots, n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr,
+                           base, ctx->d_counts.ptr, ctx->d_partials.ptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-template <bool W, bool P>
-hipError_t launch_exact_r(int r, yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots,
+template <bool W, bool P, bool F>
+hipError_t launch_count_r(int r, yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots,
                           int n_bins, int n_edges, int64_t n_items, size_t lds) {
     switch (r) {
-        case 1: return launch_exact<1, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
-        case 2: return launch_exact<2, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
-        default: return launch_exact<4, W, P>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+        case 1: return launch_count<1, W, P, F>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+        case 2: return launch_count<2, W, P, F>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+        default: return launch_count<4, W, P, F>(ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
     }
+}
+
+template <bool W>
+hipError_t launch_count_any(bool priv, bool filter, int r, yawhip_ctx *ctx, const yawhip_catalog *c1,
+                            const yawhip_catalog *c2, int n_slots, int n_bins, int n_edges, int64_t n_items, size_t lds) {
+    if (priv)
+        return filter ? launch_count_r<W, true, true>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds)
+                      : launch_count_r<W, true, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+    return filter ? launch_count_r<W, false, true>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds)
+                  : launch_count_r<W, false, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
 }
 
 inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
@@ -364,6 +441,7 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_jobs.release();
     ctx->d_prefix.release();
     ctx->d_t.release();
+    ctx->d_dthr.release();
     ctx->d_counts.release();
     ctx->d_sums.release();
     ctx->d_partials.release();
@@ -411,6 +489,10 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
     c->n_patches = n_patches;
     c->nb = n_bins_or_1;
     c->h_off.assign(offsets, offsets + nseg + 1);
+    for (int64_t i = 0; i < n && c->unit_norm; ++i) {
+        const double n2 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
+        if (!(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL)) c->unit_norm = false;
+    }
     const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->x), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->y), col);
@@ -479,9 +561,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (jobs[2 * j] < 0 || jobs[2 * j] >= c1->n_patches || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= c1->n_patches)
             return fail(YAWHIP_ERR_INVALID, "job %d has a patch id outside [0,%d)", j, c1->n_patches);
     if (kernel == YAWHIP_KERNEL_AUTO) kernel = ctx->default_kernel;
-    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_EXACT;
-    if (kernel != YAWHIP_KERNEL_EXACT)
+    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_FILTER;
+    if (kernel != YAWHIP_KERNEL_EXACT && kernel != YAWHIP_KERNEL_FILTER)
         return fail(YAWHIP_ERR_INVALID, "kernel %d is not available in this build", kernel);
+    // the FP32 pre-filter assumes unit vectors; anything else is counted by the plain FP64 kernel
+    if (kernel == YAWHIP_KERNEL_FILTER && !(c1->unit_norm && c2->unit_norm)) kernel = YAWHIP_KERNEL_EXACT;
+    const bool filter = kernel == YAWHIP_KERNEL_FILTER;
 
     const int nf = n_edges - 1;
     const int64_t n_slots = (int64_t)n_jobs * n_bins;
@@ -529,6 +614,14 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_jobs.reserve((size_t)2 * n_jobs));
     HIP_TRY(ctx->d_prefix.reserve((size_t)n_slots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
+    HIP_TRY(ctx->d_dthr.reserve((size_t)n_bins));
+    std::vector<float> dthr((size_t)n_bins);
+    for (int k = 0; k < n_bins; ++k) {  // 1 - t_max/2 - guard, rounded towards -inf
+        const double v = 1.0 - 0.5 * t[(size_t)k * n_edges + n_edges - 1] - FILTER_GUARD;
+        float f = (float)v;
+        if ((double)f > v) f = nextafterf(f, -4.0f);
+        dthr[(size_t)k] = f;
+    }
     HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * nf));
@@ -536,26 +629,27 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice,
                            ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * n_bins, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_sums.ptr, 0, sizeof(double) * n_out, ctx->stream));
 
     // LDS: two stages + thresholds + histogram(s)
-    const size_t lds_fixed = 2 * STAGE * sizeof(Obj) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
+    const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_items > 0) {
         if (run_unweighted) {
             const bool priv = lds_for(false, true) <= (size_t)ctx->lds_limit;
-            hipError_t e = priv ? launch_exact_r<false, true>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(false, true))
-                                : launch_exact_r<false, false>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(false, false));
+            hipError_t e = launch_count_any<false>(priv, filter, R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items,
+                                                   lds_for(false, priv));
             HIP_TRY(e);
             ++launches;
         }
         if (run_weighted) {
             const bool priv = lds_for(true, true) <= (size_t)ctx->lds_limit;
-            hipError_t e = priv ? launch_exact_r<true, true>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(true, true))
-                                : launch_exact_r<true, false>(R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items, lds_for(true, false));
+            hipError_t e = launch_count_any<true>(priv, filter, R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items,
+                                                  lds_for(true, priv));
             HIP_TRY(e);
             ++launches;
             const int thr = 256;
