@@ -32,7 +32,7 @@ def _single(xyz, w):
                 off=np.array([0, len(xyz)], dtype=np.int64))
 
 
-KERNELS = ["exact", "filter"]
+KERNELS = ["exact", "filter", "sweep"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)

@@ -9,9 +9,14 @@
 // Design (wave64, no MFMA -- K=3 distances are not a contraction and bit parity forbids a dot-product rewrite):
 //   * catalogues live in HBM as SoA float64 columns x,y,z,(w), sorted by (patch, z-bin) with a CSR
 //     offset table; every column load is a fully coalesced 512 B per wave;
+//   * inside a segment objects are kept sorted by their z coordinate (done once at upload; the ABI
+//     leaves the order inside a segment to the library);
 //   * work item = (job, bin, lane tile): a 256-thread workgroup keeps TILE = 256*R objects of the
-//     c2 segment in registers (R per lane) and streams the c1 segment through LDS in 256-object
-//     stages (register-staged double buffer), reading each streamed object as a wave-wide LDS broadcast;
+//     c2 segment in registers (R per lane) and streams a window of the c1 segment through LDS in
+//     256-object stages (register-staged double buffer), reading each streamed object as a wave-wide
+//     LDS broadcast. A builder kernel (k_build_items) turns the job table into item records; with
+//     the SWEEP path it binary-searches, per item, the z-window of the c1 segment that can hold a
+//     partner of the tile (|dz| <= sqrt(t_max)) and drops items whose window is empty;
 //   * per streamed object: 8 FP64 VALU ops + 1 compare per lane-object; a wave ballot of "s <= t_max"
 //     skips the histogram update for the >99.9 % of iterations without any pair inside the outer edge;
 //   * counters: per-lane private LDS histograms (no atomics in the loop), fixed-order tree reduction
@@ -23,6 +28,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <numeric>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -81,6 +89,81 @@ struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte 
 constexpr double FILTER_GUARD = 8.0 * 5.9604644775390625e-8;
 constexpr double UNIT_NORM_TOL = 1e-9;
 
+struct alignas(16) Item {  // one unit of work for a workgroup
+    int64_t a0;    // first lane object (c2 side)
+    int64_t b0;    // first streamed object (c1 side)
+    int32_t na;    // lane objects (<= 256*R)
+    int32_t nb;    // streamed objects
+    int32_t slot;  // job * n_bins + bin
+    int32_t pot;   // index among all potential items (slab index of weighted partial sums)
+};
+
+// ------------------------------------------------------------------------------------------------
+// Item builder: one thread per potential item (slot, lane tile).
+//   SWEEP = false: the item streams the whole c1 segment; record written at its own index.
+//   SWEEP = true : segments are sorted by z, so the tile spans [z(a0), z(a_last)] and only c1
+//                  objects with z in [zmin - rwin, zmax + rwin] can satisfy s <= t_max (s >= dz^2);
+//                  rwin[k] = sqrt(t_max[k]) * (1 + 1e-12) + 1e-15 absorbs every rounding in
+//                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
+//                  dropped; survivors are appended with one atomic per wave (order is irrelevant).
+// ------------------------------------------------------------------------------------------------
+template <bool SWEEP>
+__global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
+                                                     const int64_t *__restrict__ prefix, int n_slots, int n_bins,
+                                                     int tile, const double *__restrict__ rwin, int64_t n_pot,
+                                                     Item *__restrict__ items, unsigned long long *__restrict__ counters) {
+    const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    Item it{};
+    unsigned long long work = 0;
+    if (pot < n_pot) {
+        int lo = 0, hi = n_slots;  // slot = largest s with prefix[s] <= pot
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= pot) lo = mid; else hi = mid;
+        }
+        const int slot = lo, job = slot / n_bins, k = slot - job * n_bins;
+        const int p = jobs[2 * job], q = jobs[2 * job + 1];
+        const int k1 = c1.nb == 1 ? 0 : k, k2 = c2.nb == 1 ? 0 : k;
+        int64_t b0 = c1.off[(int64_t)p * c1.nb + k1], b1 = c1.off[(int64_t)p * c1.nb + k1 + 1];
+        const int64_t a_seg1 = c2.off[(int64_t)q * c2.nb + k2 + 1];
+        const int64_t a0 = c2.off[(int64_t)q * c2.nb + k2] + (pot - prefix[slot]) * (int64_t)tile;
+        const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
+        if (SWEEP) {
+            const double wlo = c2.z[a0] - rwin[k], whi = c2.z[a1 - 1] + rwin[k];
+            int64_t l = b0, h = b1;  // first index with z >= wlo
+            while (l < h) {
+                const int64_t m = (l + h) >> 1;
+                if (c1.z[m] < wlo) l = m + 1; else h = m;
+            }
+            const int64_t first = l;
+            h = b1;  // first index with z > whi
+            while (l < h) {
+                const int64_t m = (l + h) >> 1;
+                if (c1.z[m] <= whi) l = m + 1; else h = m;
+            }
+            b0 = first;
+            b1 = l;
+        }
+        keep = b1 > b0;
+        it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = slot; it.pot = (int32_t)pot;
+        work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
+    }
+    if (SWEEP) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+        const int lane = threadIdx.x & 63;
+        unsigned long long base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (keep) items[base + __popcll(mask & ((1ull << lane) - 1ull))] = it;
+    } else if (pot < n_pot) {
+        items[pot] = it;
+    }
+    // evaluated pairs: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
+    if ((threadIdx.x & 63) == 0 && work) atomicAdd(&counters[1], work);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pair count kernel.
 //   R         objects per lane (lane tile = 256*R objects of the c2 segment)
@@ -97,8 +180,7 @@ constexpr double UNIT_NORM_TOL = 1e-9;
 //                    s > t_max and belongs to no bin: results are bit-identical to FILTER=false.
 // ------------------------------------------------------------------------------------------------
 template <int R, bool WEIGHTED, bool PRIVATE, bool FILTER>
-__global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
-                                              const int64_t *__restrict__ prefix, int n_slots, int n_bins,
+__global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item *__restrict__ items, int n_bins,
                                               int n_edges, const double *__restrict__ t,
                                               const float *__restrict__ dthr, int64_t item_base,
                                               unsigned long long *__restrict__ out_counts,
@@ -112,21 +194,12 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const int3
 
     const int tid = threadIdx.x;
     const int nf = n_edges - 1;
-    const int64_t item = item_base + blockIdx.x;
-
-    // slot = largest s with prefix[s] <= item   (uniform binary search)
-    int lo = 0, hi = n_slots;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (prefix[mid] <= item) lo = mid; else hi = mid;
-    }
-    const int slot = lo;
-    const int job = slot / n_bins, k = slot - job * n_bins;
-    const int p = jobs[2 * job], q = jobs[2 * job + 1];
-    const int k1 = c1.nb == 1 ? 0 : k, k2 = c2.nb == 1 ? 0 : k;
-    const int64_t b0 = c1.off[(int64_t)p * c1.nb + k1], b1 = c1.off[(int64_t)p * c1.nb + k1 + 1];
-    const int64_t a_seg0 = c2.off[(int64_t)q * c2.nb + k2], a_seg1 = c2.off[(int64_t)q * c2.nb + k2 + 1];
-    const int64_t a0 = a_seg0 + (item - prefix[slot]) * (int64_t)(WG * R);
+    const Item it = items[item_base + blockIdx.x];
+    const int slot = it.slot;
+    const int k = slot % n_bins;
+    const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
+    const int64_t a0 = it.a0, a_seg1 = it.a0 + it.na;
+    const int64_t item = it.pot;
 
     // lane objects (c2 side) -> registers; padded lanes are parked far away
     double ax[R], ay[R], az[R], aw[R];
@@ -321,6 +394,9 @@ struct yawhip_ctx {
     DevBuf<int64_t> d_prefix;
     DevBuf<double> d_t;
     DevBuf<float> d_dthr;
+    DevBuf<double> d_rwin;
+    DevBuf<Item> d_items;
+    DevBuf<unsigned long long> d_ctr;   // [0] kept items, [1] evaluated pairs
     DevBuf<unsigned long long> d_counts;
     DevBuf<double> d_sums;
     DevBuf<double> d_partials;
@@ -354,8 +430,8 @@ hipError_t launch_count(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_
     for (int64_t base = 0; base < n_items; base += max_grid) {
         const int64_t g = std::min(max_grid, n_items - base);
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WG), lds_bytes, ctx->stream, view_of(c1), view_of(c2),
-                           ctx->d_jobs.ptr, ctx->d_prefix.ptr, n_slots, n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr,
-                           base, ctx->d_counts.ptr, ctx->d_partials.ptr);
+                           ctx->d_items.ptr, n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, base, ctx->d_counts.ptr,
+                           ctx->d_partials.ptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -380,6 +456,29 @@ hipError_t launch_count_any(bool priv, bool filter, int r, yawhip_ctx *ctx, cons
                       : launch_count_r<W, true, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
     return filter ? launch_count_r<W, false, true>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds)
                   : launch_count_r<W, false, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
+}
+
+// Sort every (patch, bin) segment by z (ties by original index, so the order is deterministic).
+// Returns the permutation; segments are independent, a few host threads share them.
+std::vector<int64_t> sort_segments_by_z(int64_t n, const double *z, const int64_t *offsets, int64_t nseg) {
+    std::vector<int64_t> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), (int64_t)0);
+    std::atomic<int64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t sgm = next.fetch_add(1);
+            if (sgm >= nseg) break;
+            std::sort(perm.begin() + offsets[sgm], perm.begin() + offsets[sgm + 1],
+                      [z](int64_t a, int64_t b) { return z[a] < z[b] || (z[a] == z[b] && a < b); });
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = n < (1 << 16) ? 1u : std::min(std::max(hw, 1u), 16u);
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto &th : pool) th.join();
+    return perm;
 }
 
 inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
@@ -442,6 +541,9 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_prefix.release();
     ctx->d_t.release();
     ctx->d_dthr.release();
+    ctx->d_rwin.release();
+    ctx->d_items.release();
+    ctx->d_ctr.release();
     ctx->d_counts.release();
     ctx->d_sums.release();
     ctx->d_partials.release();
@@ -493,6 +595,22 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
         const double n2 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
         if (!(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL)) c->unit_norm = false;
     }
+    // library-private order inside a segment: ascending z (enables the SWEEP windows)
+    std::vector<double> sx, sy, sz, sw;
+    try {
+        const std::vector<int64_t> perm = sort_segments_by_z(n, z, offsets, nseg);
+        auto gather = [&](const double *src, std::vector<double> &dst) {
+            dst.resize((size_t)n);
+            for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = src[perm[(size_t)i]];
+        };
+        gather(x, sx);
+        gather(y, sy);
+        gather(z, sz);
+        if (w) gather(w, sw);
+    } catch (const std::exception &ex) {
+        delete c;
+        return fail(YAWHIP_ERR_OOM, "host-side segment sort failed: %s", ex.what());
+    }
     const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->x), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->y), col);
@@ -500,11 +618,11 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
     if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->w), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->off), (size_t)(nseg + 1) * sizeof(int64_t));
     if (e == hipSuccess && n > 0) {
-        e = hipMemcpyAsync(c->x, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->z, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(c->x, sx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->y, sy.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->z, sz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && w)
-            e = hipMemcpyAsync(c->w, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(c->w, sw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->off, offsets, (size_t)(nseg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
@@ -561,12 +679,14 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (jobs[2 * j] < 0 || jobs[2 * j] >= c1->n_patches || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= c1->n_patches)
             return fail(YAWHIP_ERR_INVALID, "job %d has a patch id outside [0,%d)", j, c1->n_patches);
     if (kernel == YAWHIP_KERNEL_AUTO) kernel = ctx->default_kernel;
-    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_FILTER;
-    if (kernel != YAWHIP_KERNEL_EXACT && kernel != YAWHIP_KERNEL_FILTER)
-        return fail(YAWHIP_ERR_INVALID, "kernel %d is not available in this build", kernel);
-    // the FP32 pre-filter assumes unit vectors; anything else is counted by the plain FP64 kernel
-    if (kernel == YAWHIP_KERNEL_FILTER && !(c1->unit_norm && c2->unit_norm)) kernel = YAWHIP_KERNEL_EXACT;
-    const bool filter = kernel == YAWHIP_KERNEL_FILTER;
+    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_SWEEP;
+    if (kernel < YAWHIP_KERNEL_EXACT || kernel > YAWHIP_KERNEL_SWEEP)
+        return fail(YAWHIP_ERR_INVALID, "unknown kernel id %d", kernel);
+    // the FP32 pre-filter assumes unit vectors; anything else is evaluated pair by pair in FP64
+    const bool unit = c1->unit_norm && c2->unit_norm;
+    if (kernel == YAWHIP_KERNEL_FILTER && !unit) kernel = YAWHIP_KERNEL_EXACT;
+    const bool sweep = kernel == YAWHIP_KERNEL_SWEEP;
+    const bool filter = unit && kernel != YAWHIP_KERNEL_EXACT;
 
     const int nf = n_edges - 1;
     const int64_t n_slots = (int64_t)n_jobs * n_bins;
@@ -637,7 +757,36 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
+    const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
+    unsigned long long ctr[2] = {0ull, 0ull};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (n_pot > 0) {
+        if (n_pot >= (1ll << 31)) return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
+        HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
+        HIP_TRY(ctx->d_ctr.reserve(2));
+        HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
+        std::vector<double> rwin((size_t)n_bins);
+        for (int k = 0; k < n_bins; ++k)
+            rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
+        HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        const unsigned bgrid = (unsigned)((n_pot + 255) / 256);
+        if (sweep)
+            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
+                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_slots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
+                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+        else
+            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
+                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_slots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
+                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+        HIP_TRY(hipGetLastError());
+        ++launches;
+        HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // the grid of the count kernel = surviving items
+        n_items = sweep ? (int64_t)ctr[0] : n_pot;
+        if (run_weighted && sweep)  // dropped items leave their slab untouched
+            HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * nf, ctx->stream));
+    }
     if (n_items > 0) {
         if (run_unweighted) {
             const bool priv = lds_for(false, true) <= (size_t)ctx->lds_limit;
@@ -676,7 +825,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         stats->candidate_pairs = cand;
-        stats->evaluated_pairs = cand * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
+        stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
         stats->algorithmic_bytes = abytes;
         stats->n_workgroups = n_items;
         stats->n_launches = launches;
