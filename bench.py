@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--zbins", type=int, default=30)
     ap.add_argument("--kernel", default="auto", choices=["auto", "exact", "filter", "sweep"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--tile-r", type=int, default=0, help="objects per lane (0 = library default)")
+    ap.add_argument("--debug-no-hits", action="store_true", help="diagnostics: time the pre-filter only (wrong counts)")
     return ap.parse_args()
 
 
@@ -138,6 +140,10 @@ def main():
     from yet_another_wizz_amd import PatchLinkage, engine
 
     engine.default_kernel = args.kernel
+    if args.tile_r:
+        engine.get_context().set_option("tile_r", args.tile_r)
+    if args.debug_no_hits:
+        engine.get_context().set_option("debug_no_hits", 1)
     t_setup = time.perf_counter()
     config, ref, unk = make_catalogs(args)
     ref.build_trees(config.binning.edges, closed=config.binning.closed)

@@ -23,12 +23,14 @@ def main():
     jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)[: int(sys.argv[2]) if len(sys.argv) > 2 else 64]
     am = np.pi/10800
     t = np.tile(np.array([(2*np.sin(am/2))**2, (2*np.sin(10*am/2))**2]), (B, 1))
+    import os
+    if os.environ.get("NO_HITS"): ctx.set_option("debug_no_hits", 1)
     for kern in sys.argv[3:] or ["exact"]:
         for r in (1, 2, 4):
             ctx.set_option("tile_r", r)
             for rep in range(2):
                 counts, _, st = _lib.count_pairs(ctx, c1, c2, jobs, t, kernel=kern)
             print(f"{kern} R={r} cand={st.candidate_pairs:.3e} kernel_ms={st.kernel_ms:.2f} total_ms={st.total_ms:.2f} "
-                  f"rate={st.candidate_pairs/st.kernel_ms/1e6:.1f} Gpairs/s found={counts.sum()} wgs={st.n_workgroups}", flush=True)
+                  f"rate={st.candidate_pairs/st.kernel_ms/1e6:.1f} Gpairs/s eval={st.evaluated_pairs:.3e} evalrate={st.evaluated_pairs/st.kernel_ms/1e6:.1f} G/s found={counts.sum()} wgs={st.n_workgroups}", flush=True)
 
 main()

@@ -79,6 +79,10 @@ struct alignas(16) Obj {  // one streamed object in LDS: two 16-byte broadcast r
     double x, y, z, w;
 };
 
+struct alignas(16) ObjT {  // streamed object + inner/outer edge of its own redshift bin (merged path)
+    double x, y, z, w, tlo, thi;
+};
+
 struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte broadcast read
     float x, y, z, pad;
 };
@@ -344,6 +348,195 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-correlation fast path: c1 binned in redshift, c2 unbinned, unit vectors.
+// The c1 side is read from its *merged* layout: all bins of a patch in one z-sorted run with the
+// bin id kept per object. A work item = (job, lane tile of the c2 patch); it streams the single
+// z-window of the merged c1 patch that can hold partners of the tile, whatever their bin. Every
+// streamed object carries the pre-filter threshold of its own bin in the 4th float of its record,
+// so the inner loop is the same 15 VALU instructions per 256 pairs as k_count<FILTER>; bins only
+// matter on the rare exact path, which adds into a [B][E-1] histogram:
+//   unweighted: one LDS histogram per workgroup, uint32 LDS atomics (exact, order independent);
+//   weighted:   one float64 histogram per wave, updated by lane 0 in ballot order (deterministic).
+// One item covers all B bins, so the c2 tile is loaded once per job instead of once per (job, bin).
+// ------------------------------------------------------------------------------------------------
+struct MergedView {
+    const double *x, *y, *z, *w;  // w may be null
+    const int32_t *k;             // bin id per object
+};
+
+template <int R, bool WEIGHTED, bool NF1>
+__global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, const Item *__restrict__ items,
+                                                     int n_bins, int n_edges, const double *__restrict__ t,
+                                                     const float *__restrict__ dthr, int64_t item_base,
+                                                     unsigned long long *__restrict__ out_counts,
+                                                     double *__restrict__ partials) {
+    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
+    constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    ObjT *stage = reinterpret_cast<ObjT *>(lds_raw);                                 // [2][STAGE]
+    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw + 2 * STAGE * sizeof(ObjT));     // [2][STAGE]
+    int *stagek = reinterpret_cast<int *>(lds_raw + 2 * STAGE * (sizeof(ObjT) + sizeof(ObjF)));  // [2][STAGE]
+    double *thr = reinterpret_cast<double *>(stagek + 2 * STAGE);                    // [n_bins][n_edges]
+    HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)n_bins * n_edges);         // [NHIST][n_bins*nf]
+    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nf = n_edges - 1, nslots = n_bins * nf;
+    const Item it = items[item_base + blockIdx.x];
+    const int job = it.slot;
+    const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
+    const int64_t a0 = it.a0, a_end = it.a0 + it.na;
+
+    double ax[R], ay[R], az[R], aw[R];
+    float fx[R], fy[R], fz[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = a0 + (int64_t)r * WG + tid;
+        const bool ok = i < a_end;
+        ax[r] = ok ? c2.x[i] : PAD_COORD;
+        ay[r] = ok ? c2.y[i] : PAD_COORD;
+        az[r] = ok ? c2.z[i] : PAD_COORD;
+        aw[r] = (WEIGHTED && ok && c2.w) ? c2.w[i] : (ok ? 1.0 : 0.0);
+        fx[r] = ok ? (float)ax[r] : 0.f;  // padded lane: dot = 0, below every threshold
+        fy[r] = ok ? (float)ay[r] : 0.f;
+        fz[r] = ok ? (float)az[r] : 0.f;
+    }
+    for (int e = tid; e < n_bins * n_edges; e += WG) thr[e] = t[e];
+    for (int e = tid; e < n_bins; e += WG) dth[e] = dthr[e];
+    for (int e = tid; e < NHIST * nslots; e += WG) hist[e] = HistT(0);
+    __syncthreads();
+
+    const int64_t nb_total = b1 - b0;
+    const int nstages = (int)((nb_total + STAGE - 1) / STAGE);
+    auto fetch = [&](int64_t i, ObjT &o, int &kb) {
+        const bool ok = i < b1;
+        o.x = ok ? c1.x[i] : 0.0; o.y = ok ? c1.y[i] : 0.0; o.z = ok ? c1.z[i] : 0.0;
+        o.w = (WEIGHTED && ok && c1.w) ? c1.w[i] : 1.0;
+        kb = ok ? c1.k[i] : -1;  // -1: slot past the window
+    };
+    auto put = [&](int buf, ObjT o, int kb) {
+        o.tlo = thr[(kb >= 0 ? kb : 0) * n_edges];
+        o.thi = thr[(kb >= 0 ? kb : 0) * n_edges + n_edges - 1];
+        stage[buf * STAGE + tid] = o;
+        stagef[buf * STAGE + tid] = ObjF{(float)o.x, (float)o.y, (float)o.z, kb >= 0 ? dth[kb] : 2.0f};
+        stagek[buf * STAGE + tid] = kb >= 0 ? kb : 0;
+    };
+    {
+        ObjT o; int kb;
+        fetch(b0 + tid, o, kb);
+        put(0, o, kb);
+    }
+    __syncthreads();
+
+    for (int st = 0; st < nstages; ++st) {
+        const int cb = st & 1;
+        ObjT nxt; int nxtk = 0;
+        const bool have_next = st + 1 < nstages;
+        if (have_next) fetch(b0 + (int64_t)(st + 1) * STAGE + tid, nxt, nxtk);
+        const int64_t left = nb_total - (int64_t)st * STAGE;
+        const int n = left < STAGE ? (int)left : STAGE;
+        const ObjF *curf = stagef + cb * STAGE;
+
+        // exact evaluation of the survivors of streamed object i (d = its float32 dot products)
+        auto settle = [&](int i, const float (&d)[R], float dmin) {
+            const ObjT b = stage[cb * STAGE + i];                    // independent LDS reads: one latency
+            const int kb = __builtin_amdgcn_readfirstlane(stagek[cb * STAGE + i]);
+            int n_hits = 0;          // NF1 unweighted: hits of this object, wave-uniform
+            double wave_sum = 0.0;   // NF1 weighted: sum over the wave's hits in lane order (held by every lane)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (__builtin_amdgcn_ballot_w64(d[r] >= dmin) == 0ull) continue;  // uniform skip
+                int hslot = -1;
+                if (d[r] >= dmin) {
+                    const double dx = ax[r] - b.x;
+                    const double dy = ay[r] - b.y;
+                    const double dz = az[r] - b.z;
+                    const double xx = dx * dx;
+                    const double yy = dy * dy;
+                    const double zz = dz * dz;
+                    const double sxy = xx + yy;
+                    const double s = sxy + zz;
+                    if (s > b.tlo && s <= b.thi) {
+                        if (NF1) {
+                            hslot = kb;
+                        } else {
+                            const double *tk = thr + kb * n_edges;
+                            int cnt = 0;
+                            for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
+                            hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
+                        }
+                    }
+                }
+                unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
+                if (!WEIGHTED) {
+                    if (NF1) n_hits += __popcll(m);
+                    else if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
+                } else {
+                    const double val = aw[r] * b.w;
+                    while (m) {  // the wave's hits in lane order: deterministic summation
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
+                        const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
+                        const double v = __hiloint2double(hi32, lo32);
+                        if (NF1) {
+                            wave_sum += v;
+                        } else {
+                            const int hs = __builtin_amdgcn_readlane(hslot, l);
+                            if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += v;
+                        }
+                    }
+                }
+            }
+            if (NF1 && lane == 0) {
+                if (!WEIGHTED) {
+                    if (n_hits) atomicAdd(reinterpret_cast<unsigned int *>(hist) + kb, (unsigned int)n_hits);
+                } else if (wave_sum != 0.0) {
+                    reinterpret_cast<double *>(hist)[wave * nslots + kb] += wave_sum;
+                }
+            }
+        };
+
+        // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
+        // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
+        ObjF c0 = curf[0], c1r = curf[1];
+        for (int i = 0; i < n; i += 2) {
+            const int ip = i + 2 < STAGE ? i + 2 : STAGE - 2;
+            const ObjF n0 = curf[ip], n1 = curf[ip + 1];
+            float d0[R], d1[R];
+            float best0 = -2.f, best1 = -2.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                d0[r] = __builtin_fmaf(fz[r], c0.z, __builtin_fmaf(fy[r], c0.y, fx[r] * c0.x));
+                d1[r] = __builtin_fmaf(fz[r], c1r.z, __builtin_fmaf(fy[r], c1r.y, fx[r] * c1r.x));
+                best0 = fmaxf(best0, d0[r]);
+                best1 = fmaxf(best1, d1[r]);
+            }
+            const bool p0 = best0 >= c0.pad, p1 = best1 >= c1r.pad;
+            if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(p0) != 0ull) settle(i, d0, c0.pad);
+                if (__builtin_amdgcn_ballot_w64(p1) != 0ull) settle(i + 1, d1, c1r.pad);
+            }
+            c0 = n0;
+            c1r = n1;
+        }
+        if (have_next) put(cb ^ 1, nxt, nxtk);
+        __syncthreads();
+    }
+
+    for (int idx = tid; idx < nslots; idx += WG) {
+        if (WEIGHTED) {
+            double v = 0.0;
+            for (int wv = 0; wv < NHIST; ++wv) v += reinterpret_cast<double *>(hist)[wv * nslots + idx];
+            partials[(int64_t)it.pot * nslots + idx] = v;
+        } else {
+            const unsigned int v = reinterpret_cast<unsigned int *>(hist)[idx];
+            if (v) atomicAdd(&out_counts[(int64_t)job * nslots + idx], (unsigned long long)v);
+        }
+    }
+}
+
 // Sum the per-item slabs of every (job,bin) slot in item order (deterministic).
 __global__ void k_reduce_partials(const double *__restrict__ partials, const int64_t *__restrict__ prefix,
                                   int n_slots, int nf, double *__restrict__ out) {
@@ -388,6 +581,7 @@ struct yawhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int tile_r = 0;          // 0 = auto
+    int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
     DevBuf<int32_t> d_jobs;
@@ -411,6 +605,11 @@ struct yawhip_catalog {
     std::vector<int64_t> h_off;
     int64_t device_bytes = 0;
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
+    // merged layout of a binned catalogue: all bins of a patch in one z-sorted run (+ bin id per object)
+    double *mx = nullptr, *my = nullptr, *mz = nullptr, *mw = nullptr;
+    int32_t *mk = nullptr;
+    int64_t *moff = nullptr;  // [P+1]
+    std::vector<int64_t> h_moff;
 };
 
 namespace {
@@ -562,6 +761,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->tile_r = (int)value;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "debug_no_hits")) {
+        ctx->debug_no_hits = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "kernel")) {
         if (value < YAWHIP_KERNEL_AUTO || value > YAWHIP_KERNEL_SWEEP)
             return fail(YAWHIP_ERR_INVALID, "unknown kernel id %lld", (long long)value);
@@ -633,6 +836,45 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
                     hipGetErrorString(e));
     }
     c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
+    if (n_bins_or_1 > 1 && n > 0) {
+        // second, merged layout for the cross-correlation fast path: per patch, all bins in one z-sorted run
+        std::vector<int64_t> poff((size_t)n_patches + 1);
+        for (int p = 0; p <= n_patches; ++p) poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
+        std::vector<int32_t> kk((size_t)n), sk((size_t)n);
+        for (int64_t sgm = 0; sgm < nseg; ++sgm)
+            for (int64_t i = offsets[sgm]; i < offsets[sgm + 1]; ++i) kk[(size_t)i] = (int32_t)(sgm % n_bins_or_1);
+        {
+            const std::vector<int64_t> perm = sort_segments_by_z(n, z, poff.data(), n_patches);
+            for (int64_t i = 0; i < n; ++i) {
+                const int64_t src = perm[(size_t)i];
+                sx[(size_t)i] = x[src]; sy[(size_t)i] = y[src]; sz[(size_t)i] = z[src];
+                if (w) sw[(size_t)i] = w[src];
+                sk[(size_t)i] = kk[(size_t)src];
+            }
+        }
+        e = hipMalloc(reinterpret_cast<void **>(&c->mx), col);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->my), col);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mz), col);
+        if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->mw), col);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mk), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->moff), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(c->mx, sx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->my, sy.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->mz, sz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && w)
+            e = hipMemcpyAsync(c->mw, sw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(c->mk, sk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->moff, poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            yawhip_catalog_free(c);
+            return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (merged layout) failed: %s",
+                        hipGetErrorString(e));
+        }
+        c->h_moff = poff;
+        c->device_bytes += (int64_t)col * (w ? 4 : 3) + n * (int64_t)sizeof(int32_t) + (n_patches + 1) * (int64_t)sizeof(int64_t);
+    }
     *out = c;
     return YAWHIP_OK;
 }
@@ -645,6 +887,12 @@ int yawhip_catalog_free(yawhip_catalog *c) {
     if (c->z) (void)hipFree(c->z);
     if (c->w) (void)hipFree(c->w);
     if (c->off) (void)hipFree(c->off);
+    if (c->mx) (void)hipFree(c->mx);
+    if (c->my) (void)hipFree(c->my);
+    if (c->mz) (void)hipFree(c->mz);
+    if (c->mw) (void)hipFree(c->mw);
+    if (c->mk) (void)hipFree(c->mk);
+    if (c->moff) (void)hipFree(c->moff);
     delete c;
     return YAWHIP_OK;
 }
@@ -707,24 +955,41 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     }
     const int64_t tile = (int64_t)WG * R;
 
-    // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles
-    std::vector<int64_t> prefix((size_t)n_slots + 1);
+    // Cross-correlation fast path (k_count_merged): c1 binned, c2 unbinned, unit vectors, LDS permitting.
+    const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
+    const size_t lds_merged = 2 * STAGE * (sizeof(ObjT) + sizeof(ObjF) + sizeof(int)) + (size_t)n_bins * n_edges * sizeof(double) +
+                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)n_bins * sizeof(float) + 16;
+    const bool merged = sweep && filter && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2 &&
+                        lds_merged <= (size_t)ctx->lds_limit;
+
+    // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
+    // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
+    const int64_t n_pslots = merged ? (int64_t)n_jobs : n_slots;
+    std::vector<int64_t> prefix((size_t)n_pslots + 1);
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
     for (int j = 0; j < n_jobs; ++j) {
+        int64_t n1_all = 0;
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
-            prefix[(size_t)j * n_bins + k] = n_items;
+            if (!merged) prefix[(size_t)j * n_bins + k] = n_items;
             if (n1 > 0 && n2 > 0) {
-                n_items += (n2 + tile - 1) / tile;
+                if (!merged) n_items += (n2 + tile - 1) / tile;
                 cand += n1 * n2;
             }
+            n1_all += n1;
+        }
+        if (merged) {
+            const int64_t n2 = seg_len(c2, jobs[2 * j + 1], 0);
+            prefix[(size_t)j] = n_items;
+            if (n1_all > 0 && n2 > 0) n_items += (n2 + tile - 1) / tile;
         }
         // algorithmic bytes of a job = every object of the two patches once (Bobj * (N1 + N2))
         for (int k = 0; k < c1->nb; ++k) abytes += seg_len(c1, jobs[2 * j], k) * obj_bytes1;
         for (int k = 0; k < c2->nb; ++k) abytes += seg_len(c2, jobs[2 * j + 1], k) * obj_bytes2;
     }
-    prefix[(size_t)n_slots] = n_items;
+    prefix[(size_t)n_pslots] = n_items;
+    const int64_t slab = merged ? (int64_t)n_bins * nf : nf;  // float64 values per item of the weighted slab
 
     const bool want_counts = fine_counts != nullptr;
     const bool want_sums = fine_sums != nullptr;
@@ -732,7 +997,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
     HIP_TRY(ctx->d_jobs.reserve((size_t)2 * n_jobs));
-    HIP_TRY(ctx->d_prefix.reserve((size_t)n_slots + 1));
+    HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
     HIP_TRY(ctx->d_dthr.reserve((size_t)n_bins));
     std::vector<float> dthr((size_t)n_bins);
@@ -740,13 +1005,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         const double v = 1.0 - 0.5 * t[(size_t)k * n_edges + n_edges - 1] - FILTER_GUARD;
         float f = (float)v;
         if ((double)f > v) f = nextafterf(f, -4.0f);
-        dthr[(size_t)k] = f;
+        dthr[(size_t)k] = ctx->debug_no_hits ? 2.0f : f;
     }
     HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
-    if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * nf));
+    if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_slots + 1), hipMemcpyHostToDevice,
+    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
                            ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * n_bins, hipMemcpyHostToDevice, ctx->stream));
@@ -766,18 +1031,23 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(ctx->d_ctr.reserve(2));
         HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
         std::vector<double> rwin((size_t)n_bins);
-        for (int k = 0; k < n_bins; ++k)
+        double rwin_max = 0.0;
+        for (int k = 0; k < n_bins; ++k) {
             rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
+            rwin_max = std::max(rwin_max, rwin[(size_t)k]);
+        }
+        if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
         const unsigned bgrid = (unsigned)((n_pot + 255) / 256);
+        const CatView v1 = merged ? CatView{c1->mx, c1->my, c1->mz, c1->mw, c1->moff, 1} : view_of(c1);
         if (sweep)
-            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
-                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_slots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
-                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, v1, view_of(c2),
+                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, merged ? 1 : n_bins, (int)tile,
+                               ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr);
         else
-            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
-                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_slots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
+            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, v1, view_of(c2),
+                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr);
         HIP_TRY(hipGetLastError());
         ++launches;
@@ -785,9 +1055,51 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // the grid of the count kernel = surviving items
         n_items = sweep ? (int64_t)ctr[0] : n_pot;
         if (run_weighted && sweep)  // dropped items leave their slab untouched
-            HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * nf, ctx->stream));
+            HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
-    if (n_items > 0) {
+    if (n_items > 0 && merged) {
+        const MergedView mv{c1->mx, c1->my, c1->mz, c1->mw, c1->mk};
+        auto launch_merged = [&](bool wgt) -> hipError_t {
+            const int64_t max_grid = 1ll << 30;
+            for (int64_t base = 0; base < n_items; base += max_grid) {
+                const unsigned g = (unsigned)std::min(max_grid, n_items - base);
+#define YAW_LAUNCH_MERGED(RR, WW)                                                                                     \
+    do {                                                                                                              \
+        auto kern = nf == 1 ? k_count_merged<RR, WW, true> : k_count_merged<RR, WW, false>;                          \
+        if (lds_merged > 64 * 1024) {                                                                                 \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
+            if (ea != hipSuccess) return ea;                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, view_of(c2), ctx->d_items.ptr, n_bins, \
+                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, base, ctx->d_counts.ptr, ctx->d_partials.ptr);     \
+    } while (0)
+                if (wgt) {
+                    if (R == 1) YAW_LAUNCH_MERGED(1, true); else if (R == 2) YAW_LAUNCH_MERGED(2, true); else YAW_LAUNCH_MERGED(4, true);
+                } else {
+                    if (R == 1) YAW_LAUNCH_MERGED(1, false); else if (R == 2) YAW_LAUNCH_MERGED(2, false); else YAW_LAUNCH_MERGED(4, false);
+                }
+#undef YAW_LAUNCH_MERGED
+                hipError_t el = hipGetLastError();
+                if (el != hipSuccess) return el;
+            }
+            return hipSuccess;
+        };
+        if (run_unweighted) {
+            HIP_TRY(launch_merged(false));
+            ++launches;
+        }
+        if (run_weighted) {
+            HIP_TRY(launch_merged(true));
+            ++launches;
+            const int thr = 256;
+            const int64_t n_red = (int64_t)n_jobs * slab;
+            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_red + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_jobs, (int)slab, ctx->d_sums.ptr);
+            HIP_TRY(hipGetLastError());
+            ++launches;
+        }
+    } else if (n_items > 0) {
         if (run_unweighted) {
             const bool priv = lds_for(false, true) <= (size_t)ctx->lds_limit;
             hipError_t e = launch_count_any<false>(priv, filter, R, ctx, c1, c2, (int)n_slots, n_bins, n_edges, n_items,
