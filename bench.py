@@ -186,23 +186,32 @@ def main():
 
     if rank == 0:
         value = cand * args.steps / elapsed
-        # dominant kernel: the count kernel. Algorithmic work per evaluated pair = 8 FP64 flop
-        # (3 sub, 3 mul, 2 add; the compares are not counted), exact mode forbids FMA, so the
-        # ceiling is half of the FP64 vector peak. Rank 0's launch is representative.
+        # Dominant kernel = the count kernel; rank 0's last launch is representative. What bounds it
+        # depends on the path:
+        #   exact : every candidate pair costs 8 non-FMA FP64 flop -> half of the FP64 vector peak;
+        #   filter/sweep: every *evaluated* pair costs one FP32 mul + 2 FMA = 5 flop in the pre-filter
+        #           (the exact FP64 re-evaluation touches ~0.2 % of them) -> FP32 vector peak.
+        # Neither is HBM- or MFMA-bound; the HBM figures are reported beside it.
         k_s = max(stats.kernel_ms, 1e-9) / 1e3
         kernel_name = {1: "exact", 2: "filter", 3: "sweep"}.get(stats.kernel_used, str(stats.kernel_used))
-        achieved_tflops = stats.evaluated_pairs * 8.0 / k_s / 1e12
-        peak = FP64_VECTOR_PEAK_TFLOPS / 2.0
+        if stats.kernel_used == 1:
+            bound, flop_per_pair, peak = "valu_fp64", 8.0, FP64_VECTOR_PEAK_TFLOPS / 2.0
+            note = "FP64 vector ALU, no FMA allowed by the parity contract: 8 flop per evaluated pair"
+        else:
+            bound, flop_per_pair, peak = "valu_fp32", 5.0, FP32_VECTOR_PEAK_TFLOPS
+            note = ("FP32 vector ALU: pre-filter = mul + 2 fma (5 flop) per evaluated pair; evaluated pairs = "
+                    "candidates surviving the z-window culling; survivors of the filter are re-evaluated in exact FP64")
+        achieved_tflops = stats.evaluated_pairs * flop_per_pair / k_s / 1e12
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 traffic = json.load(f).get(f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}")
         roofline = dict(
-            bound="valu_fp64", achieved=achieved_tflops, peak=peak, unit="TFLOP/s", frac=achieved_tflops / peak,
-            traffic=traffic,
-            note="FP64 vector ALU bound, not HBM/MFMA (SURVEY.md 8(d)): 8 non-FMA FP64 flop per evaluated pair",
-            kernel=f"k_count_{kernel_name}", launch_ms=stats.kernel_ms,
+            bound=bound, achieved=achieved_tflops, peak=peak, unit="TFLOP/s", frac=achieved_tflops / peak,
+            traffic=traffic, note=note, kernel=f"k_count ({kernel_name} path)", launch_ms=stats.kernel_ms,
+            evaluated_pairs_per_launch=stats.evaluated_pairs, evaluated_pairs_per_s=stats.evaluated_pairs / k_s,
+            culled_fraction=1.0 - stats.evaluated_pairs / max(stats.candidate_pairs, 1),
             hbm_algorithmic_gbps=stats.algorithmic_bytes / k_s / 1e9, hbm_peak_gbps=HBM_PEAK_GBPS,
             hbm_frac=stats.algorithmic_bytes / k_s / 1e9 / HBM_PEAK_GBPS,
         )

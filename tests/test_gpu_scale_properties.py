@@ -1,0 +1,159 @@
+"""GPU: BASELINE.json-sized inputs checked through size-independent properties (the oracle would
+take hours here): equality of the three device code paths, role-swap symmetry, additivity over a
+split catalogue, invariance under the patch decomposition, exact weight scaling, ordered-pair
+symmetry of self counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+P, B = 16, 30
+ARCMIN = np.pi / 10800
+
+
+def _box_catalog(seed, n, with_z, side=30.0, weights=None):
+    import yet_another_wizz_amd as yaw
+
+    rng = np.random.default_rng(seed)
+    ra = rng.uniform(0.0, side, n)
+    dec = np.rad2deg(np.arcsin(rng.uniform(0.0, np.sin(np.deg2rad(side)), n)))
+    g = np.linspace(side / 8, side * 7 / 8, 4)
+    centers = yaw.AngularCoordinates(np.deg2rad(np.array([(a, d) for a in g for d in g])))
+    z = rng.uniform(0.1, 1.0, n) if with_z else None
+    return yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=weights, patch_centers=centers), (ra, dec, z)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import engine
+    from yet_another_wizz_amd.measurements import angular_plans, threshold_table
+
+    n = 1_000_000
+    ref, ref_cols = _box_catalog(101, n, True)
+    unk, unk_cols = _box_catalog(202, n, False)
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=B)
+    lref = ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    lunk = unk.build_trees(None)
+    t = threshold_table(angular_plans(config))
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    fine, stats = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
+    return dict(config=config, ref=ref, unk=unk, lref=lref, lunk=lunk, t=t, jobs=jobs, fine=fine, stats=stats,
+                ref_cols=ref_cols, unk_cols=unk_cols)
+
+
+def test_three_code_paths_agree_at_1m(setup):
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    assert s["stats"].candidate_pairs > 9e11 and s["stats"].evaluated_pairs < 0.05 * s["stats"].candidate_pairs
+    assert s["fine"].sum() > 5e7
+    f_filter, st = engine.count_fine(s["lref"], s["lunk"], s["jobs"], s["t"], kernel="filter")
+    assert st.evaluated_pairs == st.candidate_pairs
+    assert np.array_equal(f_filter, s["fine"])
+    sub = s["jobs"][::5]  # plain FP64 brute force on every 5th job
+    f_exact, _ = engine.count_fine(s["lref"], s["lunk"], sub, s["t"], kernel="exact")
+    assert np.array_equal(f_exact, s["fine"][::5])
+
+
+def test_role_swap_symmetry(setup):
+    """count(ref_p, unk_q) == count(unk_q, ref_p): lanes <-> stream, binned <-> unbinned."""
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    swapped, _ = engine.count_fine(s["lunk"], s["lref"], s["jobs"][:, ::-1].copy(), s["t"], kernel="sweep")
+    assert np.array_equal(swapped, s["fine"])
+
+
+def test_additivity_over_split_catalogue(setup):
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    ra, dec, _ = s["unk_cols"]
+    half = len(ra) // 3
+    centers = s["unk"].get_centers()
+    total = np.zeros_like(s["fine"])
+    for sl in (slice(0, half), slice(half, None)):
+        part = yaw.Catalog.from_arrays(ra[sl], dec[sl], patch_centers=s["ref"])
+        assert part.num_patches == P and centers is not None
+        f, _ = engine.count_fine(s["lref"], part.build_trees(None), s["jobs"], s["t"])
+        total += f
+        part.drop_layouts()
+    assert np.array_equal(total, s["fine"])
+
+
+def test_invariance_under_patch_decomposition(setup):
+    """Summing all patch pairs gives the count of the undivided catalogues."""
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    one = yaw.AngularCoordinates(np.deg2rad([[15.0, 15.0]]))
+    ra, dec, z = s["ref_cols"]
+    ref1 = yaw.Catalog.from_arrays(ra, dec, redshifts=z, patch_centers=one)
+    ra, dec, _ = s["unk_cols"]
+    unk1 = yaw.Catalog.from_arrays(ra, dec, patch_centers=one)
+    f, st = engine.count_fine(ref1.build_trees(s["config"].binning.edges), unk1.build_trees(None), [[0, 0]], s["t"])
+    assert np.array_equal(f[0], s["fine"].sum(axis=0))
+    assert st.candidate_pairs == len(ra) * ref1.build_trees(s["config"].binning.edges).num_records
+    ref1.drop_layouts()
+    unk1.drop_layouts()
+
+
+def test_constant_weights_scale_exactly(setup):
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    ra, dec, _ = s["unk_cols"]
+    wunk = yaw.Catalog.from_arrays(ra, dec, weights=np.full(len(ra), 2.0), patch_centers=s["ref"])
+    f, _ = engine.count_fine(s["lref"], wunk.build_trees(None), s["jobs"], s["t"])
+    assert np.array_equal(f, 2.0 * s["fine"])  # powers of two: exact in float64 whatever the summation order
+    f2, _ = engine.count_fine(s["lref"], wunk.build_trees(None), s["jobs"], s["t"])
+    assert np.array_equal(f, f2)  # run-to-run reproducible
+    wunk.drop_layouts()
+
+
+def test_self_count_is_symmetric_and_even(setup):
+    """Auto count of the binned reference: ordered pairs -> counts[p,q] == counts[q,p], diagonal even."""
+    from yet_another_wizz_amd import engine
+
+    s = setup
+    f, st = engine.count_fine(s["lref"], s["lref"], s["jobs"], s["t"])
+    full = np.zeros((P, P) + f.shape[1:])
+    full[s["jobs"][:, 0], s["jobs"][:, 1]] = f
+    assert np.array_equal(full, full.transpose(1, 0, 2, 3))
+    diag = full[np.arange(P), np.arange(P)]
+    assert np.all(diag % 2 == 0) and diag.sum() > 1e5
+    f_exact, _ = engine.count_fine(s["lref"], s["lref"], s["jobs"], s["t"], kernel="exact")
+    assert np.array_equal(f, f_exact)
+
+
+def test_headline_size_paths_agree():
+    """10M x 10M / 64 patches (BASELINE.json configs[2]): sweep == filter on a sample of jobs."""
+    import types
+
+    import bench
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import engine
+    from yet_another_wizz_amd.measurements import angular_plans, threshold_table
+
+    args = types.SimpleNamespace(n_ref=10e6, n_unk=10e6, patches=64, zbins=30)
+    config, ref, unk = bench.make_catalogs(args)
+    lref = ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    lunk = unk.build_trees(None)
+    links = yaw.PatchLinkage.from_catalogs(config, ref, unk)
+    jobs = links.get_patch_pairs(ref, unk)
+    t = threshold_table(angular_plans(config))
+    f_sweep, st = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
+    assert st.candidate_pairs > 1e13 and f_sweep.sum() > 1e8
+    sample = jobs[::40]
+    f_filter, _ = engine.count_fine(lref, lunk, sample, t, kernel="filter")
+    assert np.array_equal(f_filter, f_sweep[::40])
+    # every object pair closer than theta_max is covered by the linkage: unlinked patch pairs count zero
+    unlinked = np.array([(p, q) for p in range(0, 64, 9) for q in range(64) if q not in links.patch_links[p]][:40], dtype=np.int32)
+    f_un, _ = engine.count_fine(lref, lunk, unlinked, t, kernel="sweep")
+    assert f_un.sum() == 0
+    ref.drop_layouts()
+    unk.drop_layouts()
