@@ -46,6 +46,16 @@ namespace {
 
 constexpr int WG = 256;      // threads per workgroup = 4 waves of 64
 constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
+// Experimental: count pairs that are provably inside an annulus from the float32 dot product alone
+// (see k_count_merged::settle). Bit-identical in all parity tests, but no faster on MI355X (the exact
+// re-evaluation is latency-, not ALU-bound), so it is off by default.
+#ifndef YAW_CERTAIN
+#define YAW_CERTAIN 0
+#endif
+#ifndef YAW_MSTAGE
+#define YAW_MSTAGE 128
+#endif
+constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
@@ -83,6 +93,11 @@ struct alignas(16) ObjT {  // streamed object + inner/outer edge of its own reds
     double x, y, z, w, tlo, thi;
 };
 
+struct alignas(16) ObjG {  // merged path, read when a streamed object has survivors: "certainly inside" band + bin id
+    float d_in, d_out;
+    int kb, pad;
+};
+
 struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte broadcast read
     float x, y, z, pad;
 };
@@ -91,6 +106,7 @@ struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte 
 // a mul + 2 fma evaluation (u = 2^-24); 8 u leaves room for |a|^2 deviating from 1 by < 1e-9 and for
 // the rounding of the threshold itself.
 constexpr double FILTER_GUARD = 8.0 * 5.9604644775390625e-8;
+constexpr double CERTAIN_GUARD = 6.0 * 5.9604644775390625e-8;  // two-sided classification of the merged path
 constexpr double UNIT_NORM_TOL = 1e-9;
 
 struct alignas(16) Item {  // one unit of work for a workgroup
@@ -224,7 +240,7 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
         fy[r] = ok ? (float)ay[r] : 0.f;
         fz[r] = ok ? (float)az[r] : 0.f;
     }
-    const float dmin = FILTER ? dthr[k] : 0.f;
+    const float dmin = FILTER ? dthr[3 * k] : 0.f;
 
     for (int e = tid; e < n_edges; e += WG) thr[e] = t[(int64_t)k * n_edges + e];
     if (PRIVATE) {
@@ -368,18 +384,19 @@ struct MergedView {
 template <int R, bool WEIGHTED, bool NF1>
 __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
-                                                     const float *__restrict__ dthr, int64_t item_base,
+                                                     const float *__restrict__ dthr, double rwin, int64_t item_base,
                                                      unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    ObjT *stage = reinterpret_cast<ObjT *>(lds_raw);                                 // [2][STAGE]
-    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw + 2 * STAGE * sizeof(ObjT));     // [2][STAGE]
-    int *stagek = reinterpret_cast<int *>(lds_raw + 2 * STAGE * (sizeof(ObjT) + sizeof(ObjF)));  // [2][STAGE]
-    double *thr = reinterpret_cast<double *>(stagek + 2 * STAGE);                    // [n_bins][n_edges]
+    ObjT *stage = reinterpret_cast<ObjT *>(lds_raw);                                 // [2][MSTAGE]
+    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw + 2 * MSTAGE * sizeof(ObjT));     // [2][MSTAGE]
+    ObjG *stageg = reinterpret_cast<ObjG *>(lds_raw + 2 * MSTAGE * (sizeof(ObjT) + sizeof(ObjF)));  // [2][MSTAGE]
+    double *thr = reinterpret_cast<double *>(stageg + 2 * MSTAGE);                    // [n_bins][n_edges]
     HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)n_bins * n_edges);         // [NHIST][n_bins*nf]
-    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins]
+    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins][3]
+    constexpr bool CERTAIN = YAW_CERTAIN && NF1 && !WEIGHTED;  // two-sided float32 classification (see settle)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1, nslots = n_bins * nf;
@@ -392,7 +409,9 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     float fx[R], fy[R], fz[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t i = a0 + (int64_t)r * WG + tid;
+        // wave-contiguous assignment: wave w owns objects [w*64R, (w+1)*64R) of the z-sorted tile, so
+        // its own z-window is narrower than the workgroup's
+        const int64_t i = a0 + (int64_t)wave * (64 * R) + (int64_t)r * 64 + lane;
         const bool ok = i < a_end;
         ax[r] = ok ? c2.x[i] : PAD_COORD;
         ay[r] = ok ? c2.y[i] : PAD_COORD;
@@ -402,13 +421,31 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         fy[r] = ok ? (float)ay[r] : 0.f;
         fz[r] = ok ? (float)az[r] : 0.f;
     }
+    // z-range of this wave's lane objects (+/- the window half width), as conservative float32 bounds
+    // for comparison with the float32 z of the staged objects (monotone rounding keeps them conservative)
+    float wz_lo, wz_hi;
+    {
+        const int64_t wa0 = a0 + (int64_t)wave * (64 * R);
+        int64_t wa1 = wa0 + 64 * R;
+        if (wa1 > a_end) wa1 = a_end;
+        if (wa0 < wa1) {
+            const double lo = c2.z[wa0] - rwin, hi = c2.z[wa1 - 1] + rwin;
+            wz_lo = (float)lo;
+            if ((double)wz_lo > lo) wz_lo = nextafterf(wz_lo, -4.0f);
+            wz_hi = (float)hi;
+            if ((double)wz_hi < hi) wz_hi = nextafterf(wz_hi, 4.0f);
+        } else {  // wave without objects: empty range
+            wz_lo = 4.0f;
+            wz_hi = -4.0f;
+        }
+    }
     for (int e = tid; e < n_bins * n_edges; e += WG) thr[e] = t[e];
-    for (int e = tid; e < n_bins; e += WG) dth[e] = dthr[e];
+    for (int e = tid; e < 3 * n_bins; e += WG) dth[e] = dthr[e];
     for (int e = tid; e < NHIST * nslots; e += WG) hist[e] = HistT(0);
     __syncthreads();
 
     const int64_t nb_total = b1 - b0;
-    const int nstages = (int)((nb_total + STAGE - 1) / STAGE);
+    const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
     auto fetch = [&](int64_t i, ObjT &o, int &kb) {
         const bool ok = i < b1;
         o.x = ok ? c1.x[i] : 0.0; o.y = ok ? c1.y[i] : 0.0; o.z = ok ? c1.z[i] : 0.0;
@@ -418,11 +455,12 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     auto put = [&](int buf, ObjT o, int kb) {
         o.tlo = thr[(kb >= 0 ? kb : 0) * n_edges];
         o.thi = thr[(kb >= 0 ? kb : 0) * n_edges + n_edges - 1];
-        stage[buf * STAGE + tid] = o;
-        stagef[buf * STAGE + tid] = ObjF{(float)o.x, (float)o.y, (float)o.z, kb >= 0 ? dth[kb] : 2.0f};
-        stagek[buf * STAGE + tid] = kb >= 0 ? kb : 0;
+        stage[buf * MSTAGE + tid] = o;
+        const int kk = kb >= 0 ? kb : 0;
+        stagef[buf * MSTAGE + tid] = ObjF{(float)o.x, (float)o.y, (float)o.z, kb >= 0 ? dth[3 * kk] : 2.0f};
+        stageg[buf * MSTAGE + tid] = ObjG{dth[3 * kk + 1], dth[3 * kk + 2], kk, 0};
     };
-    {
+    if (tid < MSTAGE) {
         ObjT o; int kb;
         fetch(b0 + tid, o, kb);
         put(0, o, kb);
@@ -433,58 +471,79 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         const int cb = st & 1;
         ObjT nxt; int nxtk = 0;
         const bool have_next = st + 1 < nstages;
-        if (have_next) fetch(b0 + (int64_t)(st + 1) * STAGE + tid, nxt, nxtk);
-        const int64_t left = nb_total - (int64_t)st * STAGE;
-        const int n = left < STAGE ? (int)left : STAGE;
-        const ObjF *curf = stagef + cb * STAGE;
+        if (have_next && tid < MSTAGE) fetch(b0 + (int64_t)(st + 1) * MSTAGE + tid, nxt, nxtk);
+        const int64_t left = nb_total - (int64_t)st * MSTAGE;
+        const int n = left < MSTAGE ? (int)left : MSTAGE;
+        const ObjF *curf = stagef + cb * MSTAGE;
 
-        // exact evaluation of the survivors of streamed object i (d = its float32 dot products)
+        // Survivors of the pre-filter for streamed object i (d = its float32 dot products).
+        // CERTAIN (one annulus, unweighted): dot32 = a.b + eta with |eta| <= 5.000001 u and
+        // s = |a|^2 + |b|^2 - 2 a.b, so  d_in <= dot32 <= d_out  with d_in = fl_up(1 - t_hi/2 + 6u),
+        // d_out = fl_down(1 - t_lo/2 - 6u) proves t_lo < s_fl <= t_hi for the float64 value s_fl the exact
+        // formula would give (its own rounding is < 6e-16 relative): such pairs are counted without the
+        // FP64 evaluation. Only pairs within 6u of an edge are evaluated exactly.
         auto settle = [&](int i, const float (&d)[R], float dmin) {
-            const ObjT b = stage[cb * STAGE + i];                    // independent LDS reads: one latency
-            const int kb = __builtin_amdgcn_readfirstlane(stagek[cb * STAGE + i]);
+            const ObjG g = stageg[cb * MSTAGE + i];
+            const int kb = __builtin_amdgcn_readfirstlane(g.kb);
             int n_hits = 0;          // NF1 unweighted: hits of this object, wave-uniform
             double wave_sum = 0.0;   // NF1 weighted: sum over the wave's hits in lane order (held by every lane)
+            bool unsure[R];
+            bool any_unsure = false;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (__builtin_amdgcn_ballot_w64(d[r] >= dmin) == 0ull) continue;  // uniform skip
-                int hslot = -1;
-                if (d[r] >= dmin) {
-                    const double dx = ax[r] - b.x;
-                    const double dy = ay[r] - b.y;
-                    const double dz = az[r] - b.z;
-                    const double xx = dx * dx;
-                    const double yy = dy * dy;
-                    const double zz = dz * dz;
-                    const double sxy = xx + yy;
-                    const double s = sxy + zz;
-                    if (s > b.tlo && s <= b.thi) {
-                        if (NF1) {
-                            hslot = kb;
-                        } else {
-                            const double *tk = thr + kb * n_edges;
-                            int cnt = 0;
-                            for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
-                            hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
+                if (CERTAIN) {
+                    const bool cert = d[r] >= g.d_in && d[r] <= g.d_out;
+                    n_hits += __popcll(__builtin_amdgcn_ballot_w64(cert));
+                    unsure[r] = d[r] >= dmin && !cert;
+                } else {
+                    unsure[r] = d[r] >= dmin;
+                }
+                any_unsure |= unsure[r];
+            }
+            if (__builtin_amdgcn_ballot_w64(any_unsure) != 0ull) {
+                const ObjT b = stage[cb * MSTAGE + i];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (__builtin_amdgcn_ballot_w64(unsure[r]) == 0ull) continue;  // uniform skip
+                    int hslot = -1;
+                    if (unsure[r]) {
+                        const double dx = ax[r] - b.x;
+                        const double dy = ay[r] - b.y;
+                        const double dz = az[r] - b.z;
+                        const double xx = dx * dx;
+                        const double yy = dy * dy;
+                        const double zz = dz * dz;
+                        const double sxy = xx + yy;
+                        const double s = sxy + zz;
+                        if (s > b.tlo && s <= b.thi) {
+                            if (NF1) {
+                                hslot = kb;
+                            } else {
+                                const double *tk = thr + kb * n_edges;
+                                int cnt = 0;
+                                for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
+                                hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
+                            }
                         }
                     }
-                }
-                unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
-                if (!WEIGHTED) {
-                    if (NF1) n_hits += __popcll(m);
-                    else if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
-                } else {
-                    const double val = aw[r] * b.w;
-                    while (m) {  // the wave's hits in lane order: deterministic summation
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
-                        const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
-                        const double v = __hiloint2double(hi32, lo32);
-                        if (NF1) {
-                            wave_sum += v;
-                        } else {
-                            const int hs = __builtin_amdgcn_readlane(hslot, l);
-                            if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += v;
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
+                    if (!WEIGHTED) {
+                        if (NF1) n_hits += __popcll(m);
+                        else if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
+                    } else {
+                        const double val = aw[r] * b.w;
+                        while (m) {  // the wave's hits in lane order: deterministic summation
+                            const int l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
+                            const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
+                            const double v = __hiloint2double(hi32, lo32);
+                            if (NF1) {
+                                wave_sum += v;
+                            } else {
+                                const int hs = __builtin_amdgcn_readlane(hslot, l);
+                                if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += v;
+                            }
                         }
                     }
                 }
@@ -500,9 +559,20 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
 
         // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
         // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
-        ObjF c0 = curf[0], c1r = curf[1];
-        for (int i = 0; i < n; i += 2) {
-            const int ip = i + 2 < STAGE ? i + 2 : STAGE - 2;
+        // this wave's sub-range of the (z-sorted) stage: entries below wz_lo / above wz_hi cannot pair with it
+        int i_lo = 0, i_hi = 0;
+#pragma unroll
+        for (int j = 0; j < MSTAGE / 64; ++j) {
+            const int e = j * 64 + lane;
+            const float ze = curf[e].z;
+            i_lo += __popcll(__builtin_amdgcn_ballot_w64(e < n && ze < wz_lo));
+            i_hi += __popcll(__builtin_amdgcn_ballot_w64(e < n && ze <= wz_hi));
+        }
+        i_lo &= ~1;
+        if (i_lo > MSTAGE - 2) i_lo = MSTAGE - 2;  // keeps the first read inside the stage; the loop is then empty
+        ObjF c0 = curf[i_lo], c1r = curf[i_lo + 1];
+        for (int i = i_lo; i < i_hi; i += 2) {
+            const int ip = i + 2 < MSTAGE ? i + 2 : MSTAGE - 2;
             const ObjF n0 = curf[ip], n1 = curf[ip + 1];
             float d0[R], d1[R];
             float best0 = -2.f, best1 = -2.f;
@@ -521,7 +591,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             c0 = n0;
             c1r = n1;
         }
-        if (have_next) put(cb ^ 1, nxt, nxtk);
+        if (have_next && tid < MSTAGE) put(cb ^ 1, nxt, nxtk);
         __syncthreads();
     }
 
@@ -957,8 +1027,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
 
     // Cross-correlation fast path (k_count_merged): c1 binned, c2 unbinned, unit vectors, LDS permitting.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
-    const size_t lds_merged = 2 * STAGE * (sizeof(ObjT) + sizeof(ObjF) + sizeof(int)) + (size_t)n_bins * n_edges * sizeof(double) +
-                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)n_bins * sizeof(float) + 16;
+    const size_t lds_merged = 2 * MSTAGE * (sizeof(ObjT) + sizeof(ObjF) + sizeof(ObjG)) + (size_t)n_bins * n_edges * sizeof(double) +
+                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)3 * n_bins * sizeof(float) + 16;
     const bool merged = sweep && filter && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2 &&
                         lds_merged <= (size_t)ctx->lds_limit;
 
@@ -999,13 +1069,15 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_jobs.reserve((size_t)2 * n_jobs));
     HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
-    HIP_TRY(ctx->d_dthr.reserve((size_t)n_bins));
-    std::vector<float> dthr((size_t)n_bins);
-    for (int k = 0; k < n_bins; ++k) {  // 1 - t_max/2 - guard, rounded towards -inf
-        const double v = 1.0 - 0.5 * t[(size_t)k * n_edges + n_edges - 1] - FILTER_GUARD;
-        float f = (float)v;
-        if ((double)f > v) f = nextafterf(f, -4.0f);
-        dthr[(size_t)k] = ctx->debug_no_hits ? 2.0f : f;
+    HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
+    std::vector<float> dthr((size_t)3 * n_bins);  // per bin: pre-filter threshold, certain-band lower / upper bound
+    auto round_down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -4.0f); return f; };
+    auto round_up = [](double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, 4.0f); return f; };
+    for (int k = 0; k < n_bins; ++k) {
+        const double tlo = t[(size_t)k * n_edges], thi = t[(size_t)k * n_edges + n_edges - 1];
+        dthr[(size_t)3 * k] = ctx->debug_no_hits ? 2.0f : round_down(1.0 - 0.5 * thi - FILTER_GUARD);
+        dthr[(size_t)3 * k + 1] = round_up(1.0 - 0.5 * thi + CERTAIN_GUARD);
+        dthr[(size_t)3 * k + 2] = round_down(1.0 - 0.5 * tlo - CERTAIN_GUARD);
     }
     HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
@@ -1014,7 +1086,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
                            ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * n_bins, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * 3 * n_bins, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_sums.ptr, 0, sizeof(double) * n_out, ctx->stream));
 
@@ -1022,6 +1094,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
+    double rwin_max = 0.0;  // widest z-window half width over the bins
     const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
     unsigned long long ctr[2] = {0ull, 0ull};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1031,7 +1104,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(ctx->d_ctr.reserve(2));
         HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
         std::vector<double> rwin((size_t)n_bins);
-        double rwin_max = 0.0;
         for (int k = 0; k < n_bins; ++k) {
             rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
             rwin_max = std::max(rwin_max, rwin[(size_t)k]);
@@ -1072,7 +1144,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, view_of(c2), ctx->d_items.ptr, n_bins, \
-                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, base, ctx->d_counts.ptr, ctx->d_partials.ptr);     \
+                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, rwin_max, base, ctx->d_counts.ptr,               \
+                           ctx->d_partials.ptr);                                                                      \
     } while (0)
                 if (wgt) {
                     if (R == 1) YAW_LAUNCH_MERGED(1, true); else if (R == 2) YAW_LAUNCH_MERGED(2, true); else YAW_LAUNCH_MERGED(4, true);
