@@ -1,0 +1,100 @@
+"""The on-disk input contract (reference src/yaw/catalog/patch.py:164-178, datachunk.py:47-117,
+catalog.py:325-331): a cache written by the reference is read back, and a cache written here holds
+the same records in the same format. tests/golden/refcache/ was written by the reference (tools/make_golden.py)."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+import yet_another_wizz_amd as yaw
+from conftest import GOLDEN, load_golden
+from yet_another_wizz_amd import engine
+
+REFCACHE = os.path.join(GOLDEN, "refcache")
+
+
+def test_read_reference_cache():
+    exp = load_golden("refcache_expect.npz")
+    cat = yaw.Catalog(REFCACHE)
+    assert cat.num_patches == 4 and cat.has_weights and cat.has_redshifts
+    assert np.array_equal(np.array(cat.get_num_records()), exp["meta.num_records"])
+    assert np.array_equal(cat.get_centers().data, exp["meta.centers"])  # read from meta.yml: exact
+    assert np.array_equal(cat.get_radii().data, exp["meta.radii"])
+    np.testing.assert_allclose(np.array(cat.get_sum_weights()), exp["meta.sum_weights"], rtol=1e-15)
+    # same objects as the input frame (the reference stores radian)
+    assert np.array_equal(np.sort(np.concatenate([cat[i].redshifts for i in range(4)])), np.sort(exp["input.z"]))
+    np.testing.assert_allclose(np.sort(np.concatenate([cat[i].coords.ra for i in range(4)])),
+                               np.sort(np.deg2rad(exp["input.ra"])), rtol=0, atol=0)
+
+
+def test_written_cache_is_format_compatible(tmp_path):
+    exp = load_golden("refcache_expect.npz")
+    frame = dict(ra=exp["input.ra"], dec=exp["input.dec"], z=exp["input.z"], w=exp["input.w"])
+    out = tmp_path / "mine"
+    cat = yaw.Catalog.from_dataframe(out, frame, ra_name="ra", dec_name="dec", weight_name="w", redshift_name="z",
+                                     patch_centers=yaw.AngularCoordinates(exp["patch_centers"]))
+    assert filecmp.cmp(out / "patch_ids.bin", os.path.join(REFCACHE, "patch_ids.bin"), shallow=False)
+    from yet_another_wizz_amd.catalog import read_patch_file
+
+    for pid in range(4):
+        mine, theirs = out / f"patch_{pid}" / "data.bin", os.path.join(REFCACHE, f"patch_{pid}", "data.bin")
+        assert os.path.getsize(mine) == os.path.getsize(theirs)
+        with open(mine, "rb") as f, open(theirs, "rb") as g:
+            assert f.read(1) == g.read(1)  # header byte: which columns are present
+        a, b = read_patch_file(mine), read_patch_file(theirs)
+        assert list(a) == list(b) == ["ra", "dec", "weights", "redshifts"]
+        # same records bit for bit; the order inside a patch is not defined by the reference
+        # (its groupby uses an unstable argsort, utils/misc.py:54-59)
+        rows_a = np.column_stack([a[c] for c in a])
+        rows_b = np.column_stack([b[c] for c in b])
+        assert np.array_equal(rows_a[np.lexsort(rows_a.T)], rows_b[np.lexsort(rows_b.T)]), pid
+    back = yaw.Catalog(out)
+    assert back.get_num_records() == cat.get_num_records()
+    np.testing.assert_allclose(back.get_centers().data, exp["meta.centers"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(back.get_radii().data, exp["meta.radii"], rtol=1e-12)
+    with pytest.raises(FileExistsError):
+        cat.to_cache(out)
+    cat.to_cache(out, overwrite=True)
+    with pytest.raises(OSError):
+        yaw.Catalog(tmp_path / "missing")
+
+
+def test_cache_catalog_runs_through_the_driver(monkeypatch):
+    """A catalogue restored from a reference cache gives the same counts as one built from the frame."""
+    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    exp = load_golden("refcache_expect.npz")
+    frame = dict(ra=exp["input.ra"], dec=exp["input.dec"], z=exp["input.z"], w=exp["input.w"])
+    centers = yaw.AngularCoordinates(exp["patch_centers"])
+    kw = dict(ra_name="ra", dec_name="dec", weight_name="w", patch_centers=centers)
+    config = yaw.Configuration.create(rmin=0.5, rmax=8.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=4)
+    unk = yaw.Catalog.from_dataframe(None, frame, **kw)
+    rnd = yaw.Catalog.from_dataframe(None, frame, **kw)
+    a = yaw.crosscorrelate(config, yaw.Catalog(REFCACHE), unk, unk_rand=rnd)[0]
+    b = yaw.crosscorrelate(config, yaw.Catalog.from_dataframe(None, frame, redshift_name="z", **kw), unk, unk_rand=rnd)[0]
+    # weighted sums: same pairs, but the cache holds the objects in another order -> last-bit differences
+    np.testing.assert_allclose(a.dd.counts.counts, b.dd.counts.counts, rtol=1e-12, atol=0)
+    assert a.dd.counts.counts.sum() > 0
+    np.testing.assert_allclose(a.dr.sum_weights.sum_weights1, b.dr.sum_weights.sum_weights1, rtol=1e-13)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference sources only exist in the build container")
+def test_reference_reads_our_cache(tmp_path):
+    """Other direction, build container only: the reference restores a cache written here."""
+    import subprocess
+    import sys
+
+    exp = load_golden("refcache_expect.npz")
+    frame = dict(ra=exp["input.ra"], dec=exp["input.dec"], z=exp["input.z"], w=exp["input.w"])
+    out = tmp_path / "mine"
+    cat = yaw.Catalog.from_dataframe(out, frame, ra_name="ra", dec_name="dec", weight_name="w", redshift_name="z",
+                                     patch_centers=yaw.AngularCoordinates(exp["patch_centers"]))
+    code = (
+        "import sys; sys.path.insert(0, 'tools'); from ref_loader import load_reference; yaw = load_reference();"
+        f"c = yaw.Catalog('{out}'); print(c.get_num_records(), c.has_weights, c.has_redshifts, c.get_radii().data.tolist())"
+    )
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(GOLDEN + "/../.."),
+                         timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert str(cat.get_num_records()) in res.stdout and "True True" in res.stdout

@@ -312,9 +312,30 @@ def make_2dflens(tmp):
     save("twodflens.npz", **out)
 
 
+def make_refcache(tmp):
+    """A small catalogue cache written by the reference (data.bin / meta.yml / patch_ids.bin): the
+    on-disk input contract of the path (patch.py:164-178, catalog.py:325-331)."""
+    rng = np.random.default_rng(4242)
+    df = box_catalog_frame(rng, 900, 100.0, 104.0, 20.0, 23.0, redshifts=True, weights=True)
+    centers = grid_centers(100.0, 104.0, 20.0, 23.0, 2, 2)
+    path = os.path.join(tmp, "refcache")
+    cat = yaw.Catalog.from_dataframe(path, df, ra_name="ra", dec_name="dec", weight_name="w", redshift_name="z",
+                                     patch_centers=AngularCoordinates(centers), overwrite=True)
+    dest = os.path.join(OUT, "refcache")
+    shutil.rmtree(dest, ignore_errors=True)
+    shutil.copytree(path, dest)
+    out = {}
+    frame_arrays("input", df, out)
+    catalog_meta("meta", cat, out)
+    out["patch_centers"] = centers
+    save("refcache_expect.npz", **out)
+    print("refcache files:", sorted(os.listdir(dest)), sorted(os.listdir(os.path.join(dest, "patch_0"))))
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="yawgolden_", dir="/dev/shm")
     try:
+        make_refcache(tmp)
         make_greatcircle()
         make_single_job()
         make_full(tmp)

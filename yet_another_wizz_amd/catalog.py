@@ -81,6 +81,38 @@ def kmeans_centers(xyz, weights, num: int, *, seed: int = 12345, iterations: int
     return AngularCoordinates.from_3d(centers)
 
 
+# ---------------------------------------------------------------------------------------------
+# On-disk cache format of the reference (read and written unchanged so that caches are
+# interchangeable):  <dir>/patch_ids.bin  int16 ids (catalog.py:325-331,529-530),
+# <dir>/patch_<id>/data.bin  1 header byte + row-major float64 records (patch.py:164-178,
+# datachunk.py:47,74-117), <dir>/patch_<id>/meta.yml (patch.py:149-161).
+PATCH_INFO_FILE = "patch_ids.bin"
+PATCH_NAME_TEMPLATE = "patch_{:d}"
+PATCH_DATA_FILE = "data.bin"
+PATCH_META_FILE = "meta.yml"
+_ATTR_BITS = (("ra", 0), ("dec", 1), ("weights", 2), ("redshifts", 3), ("patch_ids", 4), ("kappa", 5))
+
+
+def read_patch_file(path):
+    """data.bin -> dict of float64 columns (header byte: bit set = column present)."""
+    with open(path, "rb") as f:
+        flags = int.from_bytes(f.read(1), byteorder="big")
+        fields = [name for name, bit in _ATTR_BITS if flags & (1 << bit)]
+        raw = np.fromfile(f, dtype=np.float64)
+    if "ra" not in fields or "dec" not in fields or len(raw) % len(fields):
+        raise ValueError(f"not a patch data file: {path}")
+    table = raw.reshape(-1, len(fields))
+    return {name: table[:, i].copy() for i, name in enumerate(fields)}
+
+
+def write_patch_file(path, ra, dec, weights=None, redshifts=None) -> None:
+    cols = [ra, dec] + [c for c in (weights, redshifts) if c is not None]
+    flags = 0b11 | (int(weights is not None) << 2) | (int(redshifts is not None) << 3)
+    with open(path, "wb") as f:
+        f.write(flags.to_bytes(1, byteorder="big"))
+        np.column_stack(cols).astype(np.float64).tofile(f)
+
+
 class Metadata:
     """Patch summary used to link patches (mirror of patch.py:44-161)."""
 
@@ -192,9 +224,48 @@ class PatchLayout:
 class Catalog(Mapping):
     """Catalogue of points on the sphere, split into P spatial patches with ids 0..P-1."""
 
-    def __init__(self, ra, dec, *, patch_ids, num_patches: int | None = None, weights=None, redshifts=None,
-                 patch_centers: AngularCoordinates | None = None, cache_directory=None) -> None:
-        """Low-level constructor; coordinates in radian. Prefer the ``from_*`` constructors."""
+    def __init__(self, cache_directory, *, max_workers: int | None = None) -> None:
+        """Restore a catalogue from a cache directory written by the reference or by :meth:`to_cache`
+        (same call as ``yaw.Catalog(cache_directory)``, catalog.py:966-977)."""
+        directory = Path(cache_directory)
+        if not directory.exists():
+            raise OSError(f"cache directory not found: {directory}")
+        info = directory / PATCH_INFO_FILE
+        if not info.exists():
+            raise InconsistentPatchesError("patch info file not found")
+        ids = np.fromfile(info, dtype=np.int16).astype(np.int64)
+        if not np.array_equal(np.sort(ids), np.arange(len(ids))):
+            raise InconsistentPatchesError("patch IDs must be contiguous and start at 0")
+        columns, metas = [], {}
+        for pid in range(len(ids)):
+            patch_dir = directory / PATCH_NAME_TEMPLATE.format(pid)
+            columns.append(read_patch_file(patch_dir / PATCH_DATA_FILE))
+            meta_file = patch_dir / PATCH_META_FILE
+            if meta_file.exists():
+                import yaml
+
+                with meta_file.open() as f:
+                    metas[pid] = yaml.safe_load(f)
+        present = [tuple(sorted(c)) for c in columns]
+        if any(p != present[0] for p in present):
+            raise InconsistentPatchesError("data columns are not consistent between patches")
+
+        def joined(name):
+            return np.concatenate([c[name] for c in columns]) if name in columns[0] else None
+
+        self._setup(joined("ra"), joined("dec"), patch_ids=np.repeat(np.arange(len(ids)), [len(c["ra"]) for c in columns]),
+                    num_patches=len(ids), weights=joined("weights"), redshifts=joined("redshifts"),
+                    cache_directory=directory, stored_meta=metas)
+
+    @classmethod
+    def _from_columns(cls, ra, dec, **kwargs):
+        new = cls.__new__(cls)
+        new._setup(ra, dec, **kwargs)
+        return new
+
+    def _setup(self, ra, dec, *, patch_ids, num_patches: int | None = None, weights=None, redshifts=None,
+               patch_centers: AngularCoordinates | None = None, cache_directory=None, stored_meta=None) -> None:
+        """Common initialiser; coordinates in radian."""
         ra = np.asarray_chkfinite(ra, dtype=np.float64)
         dec = np.asarray_chkfinite(dec, dtype=np.float64)
         patch_ids = np.asarray(patch_ids)
@@ -228,17 +299,23 @@ class Catalog(Mapping):
         for pid in range(num):
             lo, hi = int(self._patch_off[pid]), int(self._patch_off[pid + 1])
             coords = AngularCoordinates(np.column_stack([self._ra[lo:hi], self._dec[lo:hi]]))
-            meta = Metadata.compute(
-                coords,
-                weights=None if self._w is None else self._w[lo:hi],
-                center=None if patch_centers is None else patch_centers[pid],
-            )
+            if stored_meta and pid in stored_meta:  # meta.yml of the cache (patch.py:359-362)
+                m = stored_meta[pid]
+                meta = Metadata(num_records=int(m["num_records"]), sum_weights=float(m["sum_weights"]),
+                                center=AngularCoordinates(m["center"]), radius=AngularDistances(m["radius"]))
+            else:
+                meta = Metadata.compute(
+                    coords,
+                    weights=None if self._w is None else self._w[lo:hi],
+                    center=None if patch_centers is None else patch_centers[pid],
+                )
             self._patches[pid] = Patch(self, lo, hi, meta)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
     def from_arrays(cls, ra, dec, *, weights=None, redshifts=None, patch_centers=None, patch_ids=None,
-                    patch_num: int | None = None, degrees: bool = True, cache_directory=None, probe_size: int = -1):
+                    patch_num: int | None = None, degrees: bool = True, cache_directory=None, overwrite: bool = False,
+                    probe_size: int = -1):
         """Build from plain arrays. One of ``patch_centers`` (nearest-centre assignment),
         ``patch_ids`` (pre-assigned, contiguous from 0) or ``patch_num`` (k-means) is required, with
         that precedence (``PatchMode.determine``, catalog.py:95-167)."""
@@ -272,8 +349,11 @@ class Catalog(Mapping):
             x, y, z = radec_to_xyz(ra, dec)
             patch_ids = nearest_center(np.column_stack([x, y, z]), centers.to_3d())
             num = len(centers)
-        return cls(ra, dec, patch_ids=patch_ids, num_patches=num, weights=weights, redshifts=redshifts,
-                   patch_centers=centers, cache_directory=cache_directory)
+        new = cls._from_columns(ra, dec, patch_ids=patch_ids, num_patches=num, weights=weights, redshifts=redshifts,
+                                patch_centers=centers, cache_directory=None)
+        if cache_directory is not None:
+            new.to_cache(cache_directory, overwrite=overwrite)
+        return new
 
     @classmethod
     def from_dataframe(cls, cache_directory, dataframe, *, ra_name: str, dec_name: str, weight_name: str | None = None,
@@ -282,8 +362,9 @@ class Catalog(Mapping):
                        overwrite: bool = False, progress: bool = False, max_workers: int | None = None,
                        chunksize: int | None = None, probe_size: int = -1, **reader_kwargs):
         """Same signature as ``yaw.Catalog.from_dataframe`` (catalog.py:980-1108). ``dataframe`` may
-        be a pandas DataFrame or any mapping from column name to array. ``cache_directory`` is kept
-        for call compatibility only (nothing is written: the catalogue lives in memory and in HBM);
+        be a pandas DataFrame or any mapping from column name to array. ``cache_directory`` may be
+        ``None`` (nothing is written: the catalogue lives in memory and in HBM); a path gets a cache in
+        the reference's on-disk format, readable by both packages (``overwrite`` as in the reference).
         ``kappa_name`` (scalar-field correlations) is outside the nn pair-count path."""
         if kappa_name is not None:
             raise NotImplementedError("scalar field ('kappa') correlations are not part of the nn pair-count path")
@@ -297,7 +378,7 @@ class Catalog(Mapping):
         return cls.from_arrays(
             column(ra_name), column(dec_name), weights=column(weight_name), redshifts=column(redshift_name),
             patch_centers=patch_centers, patch_ids=column(patch_name) if use_ids else None, patch_num=patch_num,
-            degrees=degrees, cache_directory=cache_directory, probe_size=probe_size,
+            degrees=degrees, cache_directory=cache_directory, overwrite=overwrite, probe_size=probe_size,
         )
 
     @classmethod
@@ -359,6 +440,33 @@ class Catalog(Mapping):
 
     def get_radii(self) -> AngularDistances:
         return AngularDistances.from_dists(p.meta.radius for p in self.values())
+
+    # ------------------------------------------------------------------ cache on disk
+    def to_cache(self, cache_directory, *, overwrite: bool = False) -> None:
+        """Write the catalogue in the reference's cache format (``patch_ids.bin``, ``patch_<id>/data.bin``,
+        ``patch_<id>/meta.yml``); restore with ``Catalog(cache_directory)`` here or in the reference."""
+        import shutil
+
+        import yaml
+
+        directory = Path(cache_directory)
+        if directory.exists():
+            if not overwrite:
+                raise FileExistsError(f"cache directory exists and overwrite=False: {directory}")
+            if any(directory.iterdir()) and not (directory / PATCH_INFO_FILE).exists():
+                raise FileExistsError(f"not a catalog cache, cannot be overwritten: {directory}")
+            shutil.rmtree(directory)
+        directory.mkdir(parents=True)
+        np.arange(self.num_patches, dtype=np.int16).tofile(directory / PATCH_INFO_FILE)
+        for pid, patch in self._patches.items():
+            patch_dir = directory / PATCH_NAME_TEMPLATE.format(pid)
+            patch_dir.mkdir()
+            lo, hi = patch._lo, patch._hi
+            write_patch_file(patch_dir / PATCH_DATA_FILE, self._ra[lo:hi], self._dec[lo:hi],
+                             None if self._w is None else self._w[lo:hi], None if self._z is None else self._z[lo:hi])
+            with (patch_dir / PATCH_META_FILE).open("w") as f:
+                yaml.safe_dump(patch.meta.to_dict(), f, indent=4)
+        self.cache_directory = directory
 
     # ------------------------------------------------------------------ device layout
     def _unit_vectors(self):

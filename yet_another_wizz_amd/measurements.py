@@ -82,6 +82,17 @@ class PatchLinkage:
     def __init__(self, config, patch_links: dict) -> None:
         self.config = config
         self.patch_links = patch_links
+        self.last_stats = None
+        # derived once per linkage (the configuration is immutable): thresholds and job tables
+        self._plans = None
+        self._thresholds = None
+        self._job_tables: dict = {}
+
+    def _angular_setup(self):
+        if self._plans is None:
+            self._plans = angular_plans(self.config)
+            self._thresholds = threshold_table(self._plans)
+        return self._plans, self._thresholds
 
     @classmethod
     def from_catalogs(cls, config, catalog: Catalog, *catalogs: Catalog):
@@ -130,8 +141,13 @@ class PatchLinkage:
     def get_patch_pairs(self, catalog1: Catalog, catalog2: Catalog | None = None) -> np.ndarray:
         """int32[n_jobs, 2] job table (stands in for the tuple of ``PatchPair`` objects,
         measurements.py:291-305)."""
-        pairs = list(self.iter_patch_id_pairs(auto=catalog2 is None))
-        return np.array(pairs, dtype=np.int32).reshape(-1, 2)
+        auto = catalog2 is None
+        if auto not in self._job_tables:
+            pairs = list(self.iter_patch_id_pairs(auto=auto))
+            table = np.array(pairs, dtype=np.int32).reshape(-1, 2)
+            table.setflags(write=False)
+            self._job_tables[auto] = table
+        return self._job_tables[auto]
 
     # ------------------------------------------------------------------ the hot path
     def count_pairs(self, main_catalog: Catalog, *optional_catalog: Catalog, progress: bool = False,
@@ -151,8 +167,7 @@ class PatchLinkage:
         layout1, layout2 = _active_layout(main_catalog, num_bins), _active_layout(cat2, num_bins)
 
         jobs = self.get_patch_pairs(main_catalog, None if auto else cat2)
-        plans = angular_plans(self.config)
-        thresholds = threshold_table(plans)
+        plans, thresholds = self._angular_setup()
         num_fine = thresholds.shape[1] - 1
 
         # shard the independent jobs over the process group (one process per GPU)
