@@ -90,11 +90,12 @@ def test_reference_reads_our_cache(tmp_path):
     out = tmp_path / "mine"
     cat = yaw.Catalog.from_dataframe(out, frame, ra_name="ra", dec_name="dec", weight_name="w", redshift_name="z",
                                      patch_centers=yaw.AngularCoordinates(exp["patch_centers"]))
+    from conftest import ROOT
+
     code = (
-        "import sys; sys.path.insert(0, 'tools'); from ref_loader import load_reference; yaw = load_reference();"
+        f"import sys; sys.path.insert(0, '{ROOT}/tools'); from ref_loader import load_reference; yaw = load_reference();"
         f"c = yaw.Catalog('{out}'); print(c.get_num_records(), c.has_weights, c.has_redshifts, c.get_radii().data.tolist())"
     )
-    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(GOLDEN + "/../.."),
-                         timeout=120)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
     assert str(cat.get_num_records()) in res.stdout and "True True" in res.stdout
