@@ -52,6 +52,11 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 #ifndef YAW_CERTAIN
 #define YAW_CERTAIN 0
 #endif
+// Survivors of the pre-filter are queued per wave and evaluated 64 at a time (1) instead of
+// immediately under a mostly empty execution mask (0).
+#ifndef YAW_QUEUE
+#define YAW_QUEUE 1
+#endif
 #ifndef YAW_MSTAGE
 #define YAW_MSTAGE 128
 #endif
@@ -96,6 +101,11 @@ struct alignas(16) ObjT {  // streamed object + inner/outer edge of its own reds
 struct alignas(16) ObjG {  // merged path, read when a streamed object has survivors: "certainly inside" band + bin id
     float d_in, d_out;
     int kb, pad;
+};
+
+struct alignas(16) Cand {  // merged path: one queued survivor of the pre-filter (lane object + index of its partner)
+    double x, y, z;
+    int i, pad;
 };
 
 struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte broadcast read
@@ -397,6 +407,10 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)n_bins * n_edges);         // [NHIST][n_bins*nf]
     float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins][3]
     constexpr bool CERTAIN = YAW_CERTAIN && NF1 && !WEIGHTED;  // two-sided float32 classification (see settle)
+    constexpr bool QUEUE = YAW_QUEUE != 0;
+    // per-wave candidate queue (64 entries) behind the small tables, 16-byte aligned
+    Cand *candq = reinterpret_cast<Cand *>(lds_raw + (((reinterpret_cast<unsigned char *>(dth + 3 * n_bins) - lds_raw) + 15) & ~(size_t)15));
+    double *candw = reinterpret_cast<double *>(candq + WG);  // [WG] lane-object weights of the queued survivors
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1, nslots = n_bins * nf;
@@ -467,6 +481,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     }
     __syncthreads();
 
+    int qn = 0;  // entries in this wave's candidate queue (wave-uniform)
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
         ObjT nxt; int nxtk = 0;
@@ -557,6 +572,70 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             }
         };
 
+        // Queued evaluation: a survivor's owner lane appends (its float64 coordinates, index of the partner)
+        // to the wave's queue; when 64 are waiting (or the stage ends) every lane takes one and evaluates
+        // the exact predicate -- full lanes instead of one or two active ones, one LDS latency per 64
+        // survivors instead of per survivor. Queue order = (stream order, r, lane): deterministic.
+        auto drain = [&]() {
+            if (qn == 0) return;
+            int hslot = -1;
+            double val = 0.0;
+            if (lane < qn) {
+                const Cand c = candq[wave * 64 + lane];
+                const ObjT b = stage[cb * MSTAGE + c.i];
+                const int kb = stageg[cb * MSTAGE + c.i].kb;
+                const double dx = c.x - b.x;
+                const double dy = c.y - b.y;
+                const double dz = c.z - b.z;
+                const double xx = dx * dx;
+                const double yy = dy * dy;
+                const double zz = dz * dz;
+                const double sxy = xx + yy;
+                const double s = sxy + zz;
+                if (s > b.tlo && s <= b.thi) {
+                    if (NF1) {
+                        hslot = kb;
+                    } else {
+                        const double *tk = thr + kb * n_edges;
+                        int cnt = 0;
+                        for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
+                        hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
+                    }
+                    if (WEIGHTED) val = candw[wave * 64 + lane] * b.w;
+                }
+            }
+            if (!WEIGHTED) {
+                if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
+            } else {
+                unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
+                while (m) {  // lane 0 adds the hits in queue order: deterministic summation
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int hs = __builtin_amdgcn_readlane(hslot, l);
+                    const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
+                    const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
+                    if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += __hiloint2double(hi32, lo32);
+                }
+            }
+            qn = 0;
+        };
+        auto enqueue = [&](int i, const float (&d)[R], float dmin) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const bool pass = d[r] >= dmin;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                if (m == 0ull) continue;  // uniform
+                const int cnt = __popcll(m);
+                if (qn + cnt > 64) drain();
+                if (pass) {
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    candq[wave * 64 + pos] = Cand{ax[r], ay[r], az[r], i, 0};
+                    if (WEIGHTED) candw[wave * 64 + pos] = aw[r];
+                }
+                qn += cnt;
+            }
+        };
+
         // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
         // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
         // this wave's sub-range of the (z-sorted) stage: entries below wz_lo / above wz_hi cannot pair with it
@@ -585,12 +664,18 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             }
             const bool p0 = best0 >= c0.pad, p1 = best1 >= c1r.pad;
             if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {
-                if (__builtin_amdgcn_ballot_w64(p0) != 0ull) settle(i, d0, c0.pad);
-                if (__builtin_amdgcn_ballot_w64(p1) != 0ull) settle(i + 1, d1, c1r.pad);
+                if (QUEUE) {
+                    if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
+                    if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
+                } else {
+                    if (__builtin_amdgcn_ballot_w64(p0) != 0ull) settle(i, d0, c0.pad);
+                    if (__builtin_amdgcn_ballot_w64(p1) != 0ull) settle(i + 1, d1, c1r.pad);
+                }
             }
             c0 = n0;
             c1r = n1;
         }
+        if (QUEUE) drain();  // the queue refers to this stage's LDS slots
         if (have_next && tid < MSTAGE) put(cb ^ 1, nxt, nxtk);
         __syncthreads();
     }
@@ -1028,7 +1113,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // Cross-correlation fast path (k_count_merged): c1 binned, c2 unbinned, unit vectors, LDS permitting.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
     const size_t lds_merged = 2 * MSTAGE * (sizeof(ObjT) + sizeof(ObjF) + sizeof(ObjG)) + (size_t)n_bins * n_edges * sizeof(double) +
-                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)3 * n_bins * sizeof(float) + 16;
+                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)3 * n_bins * sizeof(float) + 32 +
+                              (size_t)WG * (sizeof(Cand) + sizeof(double));
     const bool merged = sweep && filter && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2 &&
                         lds_merged <= (size_t)ctx->lds_limit;
 
