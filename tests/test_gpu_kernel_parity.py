@@ -223,3 +223,54 @@ def test_non_unit_vectors_fall_back_to_exact(ctx):
     counts, _, stats = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel="filter")
     assert np.array_equal(counts, exp) and exp.sum() > 1000
     assert stats.kernel_used == _lib.KERNEL_EXACT
+
+
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+def test_merged_path_many_edges_and_bins(ctx, weights):
+    """Cross-correlation fast path (binned x unbinned) with a fine radial binning (rweight-like, E = 58)
+    and thresholds that differ per redshift bin; sweep == exact == oracle."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(2718)
+    P, B = 4, 7
+    c1 = _random_catalog(rng, 12000, P, B, weights[0] == "w", dense_box=1.2)
+    c2 = _random_catalog(rng, 15000, P, 1, weights[1] == "w", dense_box=1.2)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    t = []
+    for k in range(B):
+        lim = oracle.parse_ang_limits(np.array([0.3, 1.0]) * (1 + 0.2 * k) * np.pi / 10800,
+                                      np.array([2.0, 9.0]) * (1 + 0.2 * k) * np.pi / 10800)
+        t.append(oracle.thresholds_for(oracle.ang_bins_for(lim, -1.0, 55)))
+    t = np.stack(t)
+    assert t.shape == (B, 58)
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    for kernel in ("sweep", "exact"):
+        counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+        assert np.array_equal(counts, exp_c), kernel
+        if weights == "uu":
+            assert np.array_equal(sums, exp_c.astype(np.float64))
+        else:
+            np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+    assert exp_c.sum() > 50000 and (exp_c > 0).sum() > 0.5 * exp_c.size
+
+
+def test_many_survivors_per_object(ctx):
+    """Dense clump: thousands of lane objects within the outer edge of every streamed object, so the
+    per-wave survivor queue fills and drains many times per stage."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(31)
+    n1, n2 = 900, 5000
+    def clump(n, zbins):
+        ra = np.deg2rad(200.0 + rng.normal(0, 0.01, n)); dec = np.deg2rad(-45.0 + rng.normal(0, 0.01, n))
+        z = rng.uniform(0.1, 0.9, n)
+        return oracle.sort_catalog(ra, dec, z, None, np.zeros(n, dtype=int), 1, np.linspace(0.1, 0.9, zbins + 1) if zbins > 1 else None, "right")
+    c1, c2 = clump(n1, 3), clump(n2, 1)
+    lim = oracle.parse_ang_limits([0.2 * np.pi / 10800], [3.0 * np.pi / 10800])
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (3, 1))
+    exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
+    for kernel in ("sweep", "filter"):
+        counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel=kernel)
+        assert np.array_equal(counts, exp), kernel
+    assert exp.sum() > 0.5 * n1 * n2
