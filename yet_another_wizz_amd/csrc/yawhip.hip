@@ -46,17 +46,6 @@ namespace {
 
 constexpr int WG = 256;      // threads per workgroup = 4 waves of 64
 constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
-// Experimental: count pairs that are provably inside an annulus from the float32 dot product alone
-// (see k_count_merged::settle). Bit-identical in all parity tests, but no faster on MI355X (the exact
-// re-evaluation is latency-, not ALU-bound), so it is off by default.
-#ifndef YAW_CERTAIN
-#define YAW_CERTAIN 0
-#endif
-// Survivors of the pre-filter are queued per wave and evaluated 64 at a time (1) instead of
-// immediately under a mostly empty execution mask (0).
-#ifndef YAW_QUEUE
-#define YAW_QUEUE 1
-#endif
 #ifndef YAW_MSTAGE
 #define YAW_MSTAGE 128
 #endif
@@ -94,20 +83,6 @@ struct alignas(16) Obj {  // one streamed object in LDS: two 16-byte broadcast r
     double x, y, z, w;
 };
 
-struct alignas(16) ObjT {  // streamed object + inner/outer edge of its own redshift bin (merged path)
-    double x, y, z, w, tlo, thi;
-};
-
-struct alignas(16) ObjG {  // merged path, read when a streamed object has survivors: "certainly inside" band + bin id
-    float d_in, d_out;
-    int kb, pad;
-};
-
-struct alignas(16) Cand {  // merged path: one queued survivor of the pre-filter (lane object + index of its partner)
-    double x, y, z;
-    int i, pad;
-};
-
 struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte broadcast read
     float x, y, z, pad;
 };
@@ -116,7 +91,6 @@ struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte 
 // a mul + 2 fma evaluation (u = 2^-24); 8 u leaves room for |a|^2 deviating from 1 by < 1e-9 and for
 // the rounding of the threshold itself.
 constexpr double FILTER_GUARD = 8.0 * 5.9604644775390625e-8;
-constexpr double CERTAIN_GUARD = 6.0 * 5.9604644775390625e-8;  // two-sided classification of the merged path
 constexpr double UNIT_NORM_TOL = 1e-9;
 
 struct alignas(16) Item {  // one unit of work for a workgroup
@@ -378,13 +352,23 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 // Cross-correlation fast path: c1 binned in redshift, c2 unbinned, unit vectors.
 // The c1 side is read from its *merged* layout: all bins of a patch in one z-sorted run with the
 // bin id kept per object. A work item = (job, lane tile of the c2 patch); it streams the single
-// z-window of the merged c1 patch that can hold partners of the tile, whatever their bin. Every
-// streamed object carries the pre-filter threshold of its own bin in the 4th float of its record,
-// so the inner loop is the same 15 VALU instructions per 256 pairs as k_count<FILTER>; bins only
-// matter on the rare exact path, which adds into a [B][E-1] histogram:
-//   unweighted: one LDS histogram per workgroup, uint32 LDS atomics (exact, order independent);
-//   weighted:   one float64 histogram per wave, updated by lane 0 in ballot order (deterministic).
-// One item covers all B bins, so the c2 tile is loaded once per job instead of once per (job, bin).
+// z-window of the merged c1 patch that can hold partners of the tile, whatever their bin.
+//
+// Fast path (all pairs of the window): only float32 lives on chip. Lanes keep the float32 image of
+// their R objects (3R VGPRs); the stream is staged in LDS as 16-byte records (xf, yf, zf, pre-filter
+// threshold of the object's own bin), so per-bin scales cost nothing in the loop: 12 mul/fma +
+// 2 max3 + 1 compare per 256 pairs and streamed object, two objects per trip, next trip prefetched.
+// Each wave owns a contiguous z-chunk of the tile and skips the stage entries outside its own window.
+//
+// Survivors (a few 1e-3 of the window pairs): the owner lane pushes a 4-byte code (r, lane, stage
+// slot) on its wave's queue; when 64 are waiting (or the stage ends) every lane takes one, gathers
+// the two float64 positions from global memory (L2-hot: both were just read by this workgroup) and
+// evaluates the exact predicate -- full lanes, one memory latency per 64 survivors. Hits go to a
+// [B][E-1] histogram in LDS:
+//   unweighted: uint32 LDS atomics (exact, order independent);
+//   weighted:   one float64 histogram per wave, lane 0 adds the wave's hits in queue order
+//               (stream order, r, lane) => bit-reproducible sums.
+// One item covers all B bins, so the c2 tile is read once per job instead of once per (job, bin).
 // ------------------------------------------------------------------------------------------------
 struct MergedView {
     const double *x, *y, *z, *w;  // w may be null
@@ -400,17 +384,11 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    ObjT *stage = reinterpret_cast<ObjT *>(lds_raw);                                 // [2][MSTAGE]
-    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw + 2 * MSTAGE * sizeof(ObjT));     // [2][MSTAGE]
-    ObjG *stageg = reinterpret_cast<ObjG *>(lds_raw + 2 * MSTAGE * (sizeof(ObjT) + sizeof(ObjF)));  // [2][MSTAGE]
-    double *thr = reinterpret_cast<double *>(stageg + 2 * MSTAGE);                    // [n_bins][n_edges]
+    ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw);                                // [2][MSTAGE]
+    double *thr = reinterpret_cast<double *>(stagef + 2 * MSTAGE);                   // [n_bins][n_edges]
     HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)n_bins * n_edges);         // [NHIST][n_bins*nf]
-    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins][3]
-    constexpr bool CERTAIN = YAW_CERTAIN && NF1 && !WEIGHTED;  // two-sided float32 classification (see settle)
-    constexpr bool QUEUE = YAW_QUEUE != 0;
-    // per-wave candidate queue (64 entries) behind the small tables, 16-byte aligned
-    Cand *candq = reinterpret_cast<Cand *>(lds_raw + (((reinterpret_cast<unsigned char *>(dth + 3 * n_bins) - lds_raw) + 15) & ~(size_t)15));
-    double *candw = reinterpret_cast<double *>(candq + WG);  // [WG] lane-object weights of the queued survivors
+    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins]
+    unsigned int *candq = reinterpret_cast<unsigned int *>(dth + n_bins);            // [WG/64][64] survivor codes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1, nslots = n_bins * nf;
@@ -418,28 +396,23 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     const int job = it.slot;
     const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
     const int64_t a0 = it.a0, a_end = it.a0 + it.na;
+    // wave-contiguous assignment: wave w owns objects [w*64R, (w+1)*64R) of the z-sorted tile, so its
+    // own z-window is narrower than the workgroup's
+    const int64_t wa0 = a0 + (int64_t)wave * (64 * R);
 
-    double ax[R], ay[R], az[R], aw[R];
     float fx[R], fy[R], fz[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        // wave-contiguous assignment: wave w owns objects [w*64R, (w+1)*64R) of the z-sorted tile, so
-        // its own z-window is narrower than the workgroup's
-        const int64_t i = a0 + (int64_t)wave * (64 * R) + (int64_t)r * 64 + lane;
+        const int64_t i = wa0 + (int64_t)r * 64 + lane;
         const bool ok = i < a_end;
-        ax[r] = ok ? c2.x[i] : PAD_COORD;
-        ay[r] = ok ? c2.y[i] : PAD_COORD;
-        az[r] = ok ? c2.z[i] : PAD_COORD;
-        aw[r] = (WEIGHTED && ok && c2.w) ? c2.w[i] : (ok ? 1.0 : 0.0);
-        fx[r] = ok ? (float)ax[r] : 0.f;  // padded lane: dot = 0, below every threshold
-        fy[r] = ok ? (float)ay[r] : 0.f;
-        fz[r] = ok ? (float)az[r] : 0.f;
+        fx[r] = ok ? (float)c2.x[i] : 0.f;  // padded lane: dot = 0, below every threshold
+        fy[r] = ok ? (float)c2.y[i] : 0.f;
+        fz[r] = ok ? (float)c2.z[i] : 0.f;
     }
     // z-range of this wave's lane objects (+/- the window half width), as conservative float32 bounds
     // for comparison with the float32 z of the staged objects (monotone rounding keeps them conservative)
     float wz_lo, wz_hi;
     {
-        const int64_t wa0 = a0 + (int64_t)wave * (64 * R);
         int64_t wa1 = wa0 + 64 * R;
         if (wa1 > a_end) wa1 = a_end;
         if (wa0 < wa1) {
@@ -454,154 +427,59 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         }
     }
     for (int e = tid; e < n_bins * n_edges; e += WG) thr[e] = t[e];
-    for (int e = tid; e < 3 * n_bins; e += WG) dth[e] = dthr[e];
+    for (int e = tid; e < n_bins; e += WG) dth[e] = dthr[3 * e];
     for (int e = tid; e < NHIST * nslots; e += WG) hist[e] = HistT(0);
     __syncthreads();
 
     const int64_t nb_total = b1 - b0;
     const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
-    auto fetch = [&](int64_t i, ObjT &o, int &kb) {
-        const bool ok = i < b1;
-        o.x = ok ? c1.x[i] : 0.0; o.y = ok ? c1.y[i] : 0.0; o.z = ok ? c1.z[i] : 0.0;
-        o.w = (WEIGHTED && ok && c1.w) ? c1.w[i] : 1.0;
-        kb = ok ? c1.k[i] : -1;  // -1: slot past the window
+    auto fetch = [&](int64_t i) {  // float32 record of streamed object i; slots past the window never pass
+        ObjF o{0.f, 0.f, 0.f, 2.0f};
+        if (i < b1) o = ObjF{(float)c1.x[i], (float)c1.y[i], (float)c1.z[i], dth[c1.k[i]]};
+        return o;
     };
-    auto put = [&](int buf, ObjT o, int kb) {
-        o.tlo = thr[(kb >= 0 ? kb : 0) * n_edges];
-        o.thi = thr[(kb >= 0 ? kb : 0) * n_edges + n_edges - 1];
-        stage[buf * MSTAGE + tid] = o;
-        const int kk = kb >= 0 ? kb : 0;
-        stagef[buf * MSTAGE + tid] = ObjF{(float)o.x, (float)o.y, (float)o.z, kb >= 0 ? dth[3 * kk] : 2.0f};
-        stageg[buf * MSTAGE + tid] = ObjG{dth[3 * kk + 1], dth[3 * kk + 2], kk, 0};
-    };
-    if (tid < MSTAGE) {
-        ObjT o; int kb;
-        fetch(b0 + tid, o, kb);
-        put(0, o, kb);
-    }
+    if (tid < MSTAGE) stagef[tid] = fetch(b0 + tid);
     __syncthreads();
 
-    int qn = 0;  // entries in this wave's candidate queue (wave-uniform)
+    int qn = 0;  // entries in this wave's survivor queue (wave-uniform)
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
-        ObjT nxt; int nxtk = 0;
+        const int64_t sb0 = b0 + (int64_t)st * MSTAGE;  // global index of stage slot 0
+        ObjF nxt{};
         const bool have_next = st + 1 < nstages;
-        if (have_next && tid < MSTAGE) fetch(b0 + (int64_t)(st + 1) * MSTAGE + tid, nxt, nxtk);
+        if (have_next && tid < MSTAGE) nxt = fetch(sb0 + MSTAGE + tid);
         const int64_t left = nb_total - (int64_t)st * MSTAGE;
         const int n = left < MSTAGE ? (int)left : MSTAGE;
         const ObjF *curf = stagef + cb * MSTAGE;
 
-        // Survivors of the pre-filter for streamed object i (d = its float32 dot products).
-        // CERTAIN (one annulus, unweighted): dot32 = a.b + eta with |eta| <= 5.000001 u and
-        // s = |a|^2 + |b|^2 - 2 a.b, so  d_in <= dot32 <= d_out  with d_in = fl_up(1 - t_hi/2 + 6u),
-        // d_out = fl_down(1 - t_lo/2 - 6u) proves t_lo < s_fl <= t_hi for the float64 value s_fl the exact
-        // formula would give (its own rounding is < 6e-16 relative): such pairs are counted without the
-        // FP64 evaluation. Only pairs within 6u of an edge are evaluated exactly.
-        auto settle = [&](int i, const float (&d)[R], float dmin) {
-            const ObjG g = stageg[cb * MSTAGE + i];
-            const int kb = __builtin_amdgcn_readfirstlane(g.kb);
-            int n_hits = 0;          // NF1 unweighted: hits of this object, wave-uniform
-            double wave_sum = 0.0;   // NF1 weighted: sum over the wave's hits in lane order (held by every lane)
-            bool unsure[R];
-            bool any_unsure = false;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (CERTAIN) {
-                    const bool cert = d[r] >= g.d_in && d[r] <= g.d_out;
-                    n_hits += __popcll(__builtin_amdgcn_ballot_w64(cert));
-                    unsure[r] = d[r] >= dmin && !cert;
-                } else {
-                    unsure[r] = d[r] >= dmin;
-                }
-                any_unsure |= unsure[r];
-            }
-            if (__builtin_amdgcn_ballot_w64(any_unsure) != 0ull) {
-                const ObjT b = stage[cb * MSTAGE + i];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (__builtin_amdgcn_ballot_w64(unsure[r]) == 0ull) continue;  // uniform skip
-                    int hslot = -1;
-                    if (unsure[r]) {
-                        const double dx = ax[r] - b.x;
-                        const double dy = ay[r] - b.y;
-                        const double dz = az[r] - b.z;
-                        const double xx = dx * dx;
-                        const double yy = dy * dy;
-                        const double zz = dz * dz;
-                        const double sxy = xx + yy;
-                        const double s = sxy + zz;
-                        if (s > b.tlo && s <= b.thi) {
-                            if (NF1) {
-                                hslot = kb;
-                            } else {
-                                const double *tk = thr + kb * n_edges;
-                                int cnt = 0;
-                                for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
-                                hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
-                            }
-                        }
-                    }
-                    unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
-                    if (!WEIGHTED) {
-                        if (NF1) n_hits += __popcll(m);
-                        else if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
-                    } else {
-                        const double val = aw[r] * b.w;
-                        while (m) {  // the wave's hits in lane order: deterministic summation
-                            const int l = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
-                            const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
-                            const double v = __hiloint2double(hi32, lo32);
-                            if (NF1) {
-                                wave_sum += v;
-                            } else {
-                                const int hs = __builtin_amdgcn_readlane(hslot, l);
-                                if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += v;
-                            }
-                        }
-                    }
-                }
-            }
-            if (NF1 && lane == 0) {
-                if (!WEIGHTED) {
-                    if (n_hits) atomicAdd(reinterpret_cast<unsigned int *>(hist) + kb, (unsigned int)n_hits);
-                } else if (wave_sum != 0.0) {
-                    reinterpret_cast<double *>(hist)[wave * nslots + kb] += wave_sum;
-                }
-            }
-        };
-
-        // Queued evaluation: a survivor's owner lane appends (its float64 coordinates, index of the partner)
-        // to the wave's queue; when 64 are waiting (or the stage ends) every lane takes one and evaluates
-        // the exact predicate -- full lanes instead of one or two active ones, one LDS latency per 64
-        // survivors instead of per survivor. Queue order = (stream order, r, lane): deterministic.
+        // Exact evaluation of the queued survivors, one per lane.
         auto drain = [&]() {
             if (qn == 0) return;
             int hslot = -1;
             double val = 0.0;
             if (lane < qn) {
-                const Cand c = candq[wave * 64 + lane];
-                const ObjT b = stage[cb * MSTAGE + c.i];
-                const int kb = stageg[cb * MSTAGE + c.i].kb;
-                const double dx = c.x - b.x;
-                const double dy = c.y - b.y;
-                const double dz = c.z - b.z;
+                const unsigned int code = candq[wave * 64 + lane];
+                const int64_t ia = wa0 + (code >> 8);         // (r * 64 + lane) of the owner
+                const int64_t ib = sb0 + (code & 0xffu);      // stage slot
+                const double dx = c2.x[ia] - c1.x[ib];
+                const double dy = c2.y[ia] - c1.y[ib];
+                const double dz = c2.z[ia] - c1.z[ib];
                 const double xx = dx * dx;
                 const double yy = dy * dy;
                 const double zz = dz * dz;
                 const double sxy = xx + yy;
                 const double s = sxy + zz;
-                if (s > b.tlo && s <= b.thi) {
+                const int kb = c1.k[ib];
+                const double *tk = thr + kb * n_edges;
+                if (s > tk[0] && s <= tk[n_edges - 1]) {
                     if (NF1) {
                         hslot = kb;
                     } else {
-                        const double *tk = thr + kb * n_edges;
                         int cnt = 0;
                         for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
-                        hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > tlo
+                        hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > t[0]
                     }
-                    if (WEIGHTED) val = candw[wave * 64 + lane] * b.w;
+                    if (WEIGHTED) val = (c2.w ? c2.w[ia] : 1.0) * (c1.w ? c1.w[ib] : 1.0);
                 }
             }
             if (!WEIGHTED) {
@@ -619,6 +497,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             }
             qn = 0;
         };
+        // Owner lanes of the survivors of stage slot i push their code on the wave's queue.
         auto enqueue = [&](int i, const float (&d)[R], float dmin) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -629,15 +508,12 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
                 if (qn + cnt > 64) drain();
                 if (pass) {
                     const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    candq[wave * 64 + pos] = Cand{ax[r], ay[r], az[r], i, 0};
-                    if (WEIGHTED) candw[wave * 64 + pos] = aw[r];
+                    candq[wave * 64 + pos] = ((unsigned)(r * 64 + lane) << 8) | (unsigned)i;
                 }
                 qn += cnt;
             }
         };
 
-        // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
-        // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
         // this wave's sub-range of the (z-sorted) stage: entries below wz_lo / above wz_hi cannot pair with it
         int i_lo = 0, i_hi = 0;
 #pragma unroll
@@ -649,6 +525,8 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         }
         i_lo &= ~1;
         if (i_lo > MSTAGE - 2) i_lo = MSTAGE - 2;  // keeps the first read inside the stage; the loop is then empty
+        // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
+        // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
         ObjF c0 = curf[i_lo], c1r = curf[i_lo + 1];
         for (int i = i_lo; i < i_hi; i += 2) {
             const int ip = i + 2 < MSTAGE ? i + 2 : MSTAGE - 2;
@@ -664,19 +542,14 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             }
             const bool p0 = best0 >= c0.pad, p1 = best1 >= c1r.pad;
             if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {
-                if (QUEUE) {
-                    if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
-                    if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
-                } else {
-                    if (__builtin_amdgcn_ballot_w64(p0) != 0ull) settle(i, d0, c0.pad);
-                    if (__builtin_amdgcn_ballot_w64(p1) != 0ull) settle(i + 1, d1, c1r.pad);
-                }
+                if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
+                if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
             }
             c0 = n0;
             c1r = n1;
         }
-        if (QUEUE) drain();  // the queue refers to this stage's LDS slots
-        if (have_next && tid < MSTAGE) put(cb ^ 1, nxt, nxtk);
+        drain();  // codes refer to this stage's slots
+        if (have_next && tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + tid] = nxt;
         __syncthreads();
     }
 
@@ -1112,9 +985,9 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
 
     // Cross-correlation fast path (k_count_merged): c1 binned, c2 unbinned, unit vectors, LDS permitting.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
-    const size_t lds_merged = 2 * MSTAGE * (sizeof(ObjT) + sizeof(ObjF) + sizeof(ObjG)) + (size_t)n_bins * n_edges * sizeof(double) +
-                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)3 * n_bins * sizeof(float) + 32 +
-                              (size_t)WG * (sizeof(Cand) + sizeof(double));
+    const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)n_bins * n_edges * sizeof(double) +
+                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)n_bins * sizeof(float) +
+                              (size_t)WG * sizeof(unsigned int) + 16;
     const bool merged = sweep && filter && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2 &&
                         lds_merged <= (size_t)ctx->lds_limit;
 
@@ -1158,12 +1031,11 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
     std::vector<float> dthr((size_t)3 * n_bins);  // per bin: pre-filter threshold, certain-band lower / upper bound
     auto round_down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -4.0f); return f; };
-    auto round_up = [](double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, 4.0f); return f; };
     for (int k = 0; k < n_bins; ++k) {
-        const double tlo = t[(size_t)k * n_edges], thi = t[(size_t)k * n_edges + n_edges - 1];
+        const double thi = t[(size_t)k * n_edges + n_edges - 1];
         dthr[(size_t)3 * k] = ctx->debug_no_hits ? 2.0f : round_down(1.0 - 0.5 * thi - FILTER_GUARD);
-        dthr[(size_t)3 * k + 1] = round_up(1.0 - 0.5 * thi + CERTAIN_GUARD);
-        dthr[(size_t)3 * k + 2] = round_down(1.0 - 0.5 * tlo - CERTAIN_GUARD);
+        dthr[(size_t)3 * k + 1] = 0.f;  // reserved
+        dthr[(size_t)3 * k + 2] = 0.f;
     }
     HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
