@@ -189,7 +189,7 @@ class PatchLayout:
     This is the counterpart of ``build_trees`` (src/yaw/catalog/trees.py:365-429): objects outside
     the binning are dropped (:414), an unbinned catalogue has one segment per patch (:400-404)."""
 
-    __slots__ = ("x", "y", "z", "w", "offsets", "num_patches", "num_bins", "sum_weights", "device")
+    __slots__ = ("x", "y", "z", "w", "offsets", "num_patches", "num_bins", "sum_weights", "device", "z_extent")
 
     def __init__(self, x, y, z, w, offsets, num_patches: int, num_bins: int) -> None:
         self.x, self.y, self.z, self.w = x, y, z, w
@@ -201,6 +201,10 @@ class PatchLayout:
             seg = np.array([float(w[lo:hi].sum()) for lo, hi in zip(offsets[:-1], offsets[1:])], dtype=np.float64)
         self.sum_weights = seg.reshape(num_patches, num_bins).T.copy()  # [B_or_1, P]
         self.device = {}  # Context id -> DeviceCatalog
+        # extent of every patch along the axis the device sorts by (z): feeds the cost model that
+        # balances jobs over GPUs (the z-window culling makes flat patches cheaper than tall ones)
+        bounds = offsets[:: num_bins]
+        self.z_extent = np.array([np.ptp(z[lo:hi]) if hi > lo else 0.0 for lo, hi in zip(bounds[:-1], bounds[1:])])
 
     @property
     def weighted(self) -> bool:

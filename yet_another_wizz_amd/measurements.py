@@ -73,6 +73,21 @@ def threshold_table(plans) -> np.ndarray:
     return table
 
 
+def job_costs(layout1, layout2, jobs, thresholds, tile: int = 1024) -> np.ndarray:
+    """Estimated device work per job, used to balance jobs over GPUs.
+
+    Brute force would cost N1*N2; the z-window culling of the device path only evaluates the part
+    of patch 1 within (tile extent + 2 r_max) in z of each lane tile of patch 2, so a job costs about
+    N2 * N1 * min(1, (zext2 * tile / N2 + 2 r_max) / zext1)."""
+    n1 = layout1.segment_sizes()[jobs[:, 0]].sum(axis=1, dtype=np.float64)
+    n2 = layout2.segment_sizes()[jobs[:, 1]].sum(axis=1, dtype=np.float64)
+    r_max = float(np.sqrt(np.max(thresholds)))
+    z1 = np.maximum(layout1.z_extent[jobs[:, 0]], 1e-12)
+    z2 = layout2.z_extent[jobs[:, 1]]
+    window = np.minimum(1.0, (z2 * np.minimum(1.0, tile / np.maximum(n2, 1.0)) + 2.0 * r_max) / z1)
+    return n1 * n2 * window + 1e3 * (n1 + n2)  # + per-object cost of touching the patches at all
+
+
 class PatchLinkage:
     """Which patch pairs can contain pairs of objects within the largest scale.
 
@@ -174,10 +189,7 @@ class PatchLinkage:
         rank, size = parallel.world()
         mine = np.arange(len(jobs))
         if size > 1:
-            sizes1, sizes2 = layout1.segment_sizes(), layout2.segment_sizes()
-            cost = (sizes1[jobs[:, 0]].sum(axis=1, dtype=np.float64)
-                    * sizes2[jobs[:, 1]].sum(axis=1, dtype=np.float64))
-            mine = parallel.partition_jobs(cost, size)[rank]
+            mine = parallel.partition_jobs(job_costs(layout1, layout2, jobs, thresholds), size)[rank]
         fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds)
         self.last_stats = stats
 
