@@ -90,6 +90,14 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
                           const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
                           yawhip_catalog **out);
+/* Same, choosing the coordinate (0 = x, 1 = y, 2 = z) along which the library keeps each segment sorted
+ * for its window culling; yawhip_catalog_upload uses z. Pick the axis most perpendicular to the survey
+ * footprint (a footprint around a pole is flat in z and culls badly along it). Two catalogues counted
+ * against each other should use the same axis, otherwise the culling is skipped (results unchanged). */
+int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+                               const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
+                               int32_t sort_axis, yawhip_catalog **out);
+int yawhip_catalog_sort_axis(const yawhip_catalog *cat, int32_t *axis);
 int yawhip_catalog_free(yawhip_catalog *cat);
 /* Device bytes held by a catalogue (for memory accounting). */
 int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);

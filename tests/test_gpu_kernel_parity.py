@@ -274,3 +274,44 @@ def test_many_survivors_per_object(ctx):
         counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel=kernel)
         assert np.array_equal(counts, exp), kernel
     assert exp.sum() > 0.5 * n1 * n2
+
+
+def test_sort_axis_variants(ctx):
+    """A polar-cap footprint is flat in z; the library can sort along x or y instead. Any axis (and a
+    mismatch between the two catalogues, which only disables the culling) gives the same counts."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(77)
+    n1, n2, P, B = 20000, 30000, 3, 4
+
+    def polar(n, nb):
+        theta = np.sqrt(rng.uniform(0, 1, n)) * np.deg2rad(4.0)  # within 4 degrees of the north pole
+        phi = rng.uniform(0, 2 * np.pi, n)
+        patch = np.minimum((phi / (2 * np.pi) * P).astype(int), P - 1)
+        z = rng.uniform(0.1, 0.9, n)
+        edges = np.linspace(0.1, 0.9, nb + 1) if nb > 1 else None
+        return oracle.sort_catalog(phi, np.pi / 2 - theta, z, None, patch, P, edges, "right")
+
+    c1, c2 = polar(n1, B), polar(n2, 1)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    lim = oracle.parse_ang_limits([1.0 * np.pi / 10800], [6.0 * np.pi / 10800])
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (B, 1))
+    exp, _ = oracle.count_jobs(c1, c2, jobs, t)
+    evaluated = {}
+    for axis in (0, 1, 2):
+        d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=axis)
+        d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=axis)
+        counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="sweep")
+        assert np.array_equal(counts, exp), axis
+        assert st.kernel_used == _lib.KERNEL_SWEEP
+        evaluated[axis] = st.evaluated_pairs
+        counts, _, _ = _lib.count_pairs(ctx, d1, d1, jobs, t, kernel="sweep")  # self count, non-merged path
+        exp_self, _ = oracle.count_jobs(c1, c1, jobs, t)
+        assert np.array_equal(counts, exp_self), axis
+    assert evaluated[2] > 2 * min(evaluated[0], evaluated[1])  # z culls worst on a polar cap
+    dz = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=2)
+    dx = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=0)
+    counts, _, st = _lib.count_pairs(ctx, dz, dx, jobs, t, kernel="sweep")
+    assert np.array_equal(counts, exp) and st.kernel_used == _lib.KERNEL_FILTER and st.evaluated_pairs == st.candidate_pairs
+    with pytest.raises(_lib.YawhipError, match="sort_axis"):
+        _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=3)

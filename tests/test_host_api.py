@@ -206,3 +206,13 @@ def test_catalog_constructors():
         yaw.Catalog.from_arrays(frame["ra"], frame["dec"], patch_ids=np.where(np.arange(n) % 2, 0, 2))
     with pytest.raises(TypeError):
         yaw.Catalog.from_dataframe(None, frame, ra_name="ra", dec_name="dec", patch_centers=np.zeros((3, 2)))
+
+
+def test_sort_axis_follows_the_footprint():
+    from yet_another_wizz_amd.measurements import best_sort_axis
+
+    ones = np.ones(3)
+    assert best_sort_axis(np.array([[0.0, 0.1, 0.99], [0.1, 0.0, 0.99], [0.05, 0.05, 0.99]]), ones) in (0, 1)  # polar cap
+    assert best_sort_axis(np.array([[0.99, 0.1, 0.0], [0.98, 0.0, 0.2], [0.97, 0.2, 0.1]]), ones) in (1, 2)   # around +x
+    full = np.array([[1.0, 0, 0], [-1.0, 0, 0], [0, 1.0, 0], [0, -1.0, 0], [0, 0, 1.0], [0, 0, -1.0]])
+    assert best_sort_axis(full, np.ones(6)) == 2  # no preferred direction: keep z

@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
 
     seen = []
 
-    def counting(layout1, layout2, jobs, thresholds, *, kernel=None):
+    def counting(layout1, layout2, jobs, thresholds, *, kernel=None, sort_axis=2):
         seen.append(len(jobs))
         return helpers.oracle_count_fine(layout1, layout2, jobs, thresholds)
 

@@ -26,6 +26,8 @@ ABI_SYMBOLS = (
     "yawhip_ctx_destroy",
     "yawhip_ctx_set_option",
     "yawhip_catalog_upload",
+    "yawhip_catalog_upload_axis",
+    "yawhip_catalog_sort_axis",
     "yawhip_catalog_free",
     "yawhip_catalog_device_bytes",
     "yawhip_count_pairs",
@@ -93,6 +95,10 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_catalog_upload.argtypes = [
         _vp, ctypes.c_int64, _dp, _dp, _dp, _dp, ctypes.c_int32, ctypes.c_int32, _i64p, ctypes.POINTER(_vp),
     ]
+    lib.yawhip_catalog_upload_axis.argtypes = [
+        _vp, ctypes.c_int64, _dp, _dp, _dp, _dp, ctypes.c_int32, ctypes.c_int32, _i64p, ctypes.c_int32, ctypes.POINTER(_vp),
+    ]
+    lib.yawhip_catalog_sort_axis.argtypes = [_vp, ctypes.POINTER(ctypes.c_int32)]
     lib.yawhip_catalog_free.argtypes = [_vp]
     lib.yawhip_catalog_device_bytes.argtypes = [_vp, _i64p]
     lib.yawhip_count_pairs.argtypes = [
@@ -153,7 +159,7 @@ class Context:
 class DeviceCatalog:
     """SoA catalogue resident in HBM, sorted by (patch, bin). ``yawhip_catalog``."""
 
-    def __init__(self, ctx: Context, x, y, z, w, n_patches: int, n_bins_or_1: int, offsets):
+    def __init__(self, ctx: Context, x, y, z, w, n_patches: int, n_bins_or_1: int, offsets, sort_axis: int = 2):
         x, y, z, w = _f64(x), _f64(y), _f64(z), _f64(w)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n = len(x)
@@ -166,12 +172,13 @@ class DeviceCatalog:
         self.weighted = w is not None
         self._h = _vp()
         _check(
-            load_library().yawhip_catalog_upload(
+            load_library().yawhip_catalog_upload_axis(
                 ctx._h, n, _ptr(x, _dp), _ptr(y, _dp), _ptr(z, _dp), _ptr(w, _dp), self.n_patches, self.n_bins,
-                _ptr(offsets, _i64p), ctypes.byref(self._h),
+                _ptr(offsets, _i64p), int(sort_axis), ctypes.byref(self._h),
             ),
-            "yawhip_catalog_upload",
+            "yawhip_catalog_upload_axis",
         )
+        self.sort_axis = int(sort_axis)
 
     @property
     def device_bytes(self) -> int:

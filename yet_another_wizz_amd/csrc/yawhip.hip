@@ -77,6 +77,8 @@ struct CatView {
     const double *x, *y, *z, *w;  // w may be null
     const int64_t *off;           // [P*nb+1]
     int nb;
+    const double *key;            // the column the segments are sorted by (x, y or z)
+    int axis;                     // 0, 1, 2
 };
 
 struct alignas(16) Obj {  // one streamed object in LDS: two 16-byte broadcast reads
@@ -105,8 +107,9 @@ struct alignas(16) Item {  // one unit of work for a workgroup
 // ------------------------------------------------------------------------------------------------
 // Item builder: one thread per potential item (slot, lane tile).
 //   SWEEP = false: the item streams the whole c1 segment; record written at its own index.
-//   SWEEP = true : segments are sorted by z, so the tile spans [z(a0), z(a_last)] and only c1
-//                  objects with z in [zmin - rwin, zmax + rwin] can satisfy s <= t_max (s >= dz^2);
+//   SWEEP = true : segments are sorted by one coordinate u (the catalogue's sort axis, z by default),
+//                  so the tile spans [u(a0), u(a_last)] and only c1 objects with u in
+//                  [umin - rwin, umax + rwin] can satisfy s <= t_max (s >= du^2);
 //                  rwin[k] = sqrt(t_max[k]) * (1 + 1e-12) + 1e-15 absorbs every rounding in
 //                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
 //                  dropped; survivors are appended with one atomic per wave (order is irrelevant).
@@ -134,17 +137,17 @@ __global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, con
         const int64_t a0 = c2.off[(int64_t)q * c2.nb + k2] + (pot - prefix[slot]) * (int64_t)tile;
         const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
         if (SWEEP) {
-            const double wlo = c2.z[a0] - rwin[k], whi = c2.z[a1 - 1] + rwin[k];
+            const double wlo = c2.key[a0] - rwin[k], whi = c2.key[a1 - 1] + rwin[k];
             int64_t l = b0, h = b1;  // first index with z >= wlo
             while (l < h) {
                 const int64_t m = (l + h) >> 1;
-                if (c1.z[m] < wlo) l = m + 1; else h = m;
+                if (c1.key[m] < wlo) l = m + 1; else h = m;
             }
             const int64_t first = l;
             h = b1;  // first index with z > whi
             while (l < h) {
                 const int64_t m = (l + h) >> 1;
-                if (c1.z[m] <= whi) l = m + 1; else h = m;
+                if (c1.key[m] <= whi) l = m + 1; else h = m;
             }
             b0 = first;
             b1 = l;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         int64_t wa1 = wa0 + 64 * R;
         if (wa1 > a_end) wa1 = a_end;
         if (wa0 < wa1) {
-            const double lo = c2.z[wa0] - rwin, hi = c2.z[wa1 - 1] + rwin;
+            const double lo = c2.key[wa0] - rwin, hi = c2.key[wa1 - 1] + rwin;
             wz_lo = (float)lo;
             if ((double)wz_lo > lo) wz_lo = nextafterf(wz_lo, -4.0f);
             wz_hi = (float)hi;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
 #pragma unroll
         for (int j = 0; j < MSTAGE / 64; ++j) {
             const int e = j * 64 + lane;
-            const float ze = curf[e].z;
+            const float ze = (&curf[e].x)[c2.axis];  // float32 image of the sorted coordinate
             i_lo += __popcll(__builtin_amdgcn_ballot_w64(e < n && ze < wz_lo));
             i_hi += __popcll(__builtin_amdgcn_ballot_w64(e < n && ze <= wz_hi));
         }
@@ -633,6 +636,7 @@ struct yawhip_catalog {
     std::vector<int64_t> h_off;
     int64_t device_bytes = 0;
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
+    int axis = 2;           // coordinate the segments are sorted by (0 = x, 1 = y, 2 = z)
     // merged layout of a binned catalogue: all bins of a patch in one z-sorted run (+ bin id per object)
     double *mx = nullptr, *my = nullptr, *mz = nullptr, *mw = nullptr;
     int32_t *mk = nullptr;
@@ -642,7 +646,10 @@ struct yawhip_catalog {
 
 namespace {
 
-CatView view_of(const yawhip_catalog *c) { return CatView{c->x, c->y, c->z, c->w, c->off, c->nb}; }
+const double *key_of(const double *x, const double *y, const double *z, int axis) { return axis == 0 ? x : (axis == 1 ? y : z); }
+CatView view_of(const yawhip_catalog *c) {
+    return CatView{c->x, c->y, c->z, c->w, c->off, c->nb, key_of(c->x, c->y, c->z, c->axis), c->axis};
+}
 
 template <int R, bool W, bool P, bool F>
 hipError_t launch_count(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int n_slots, int n_bins,
@@ -685,9 +692,9 @@ hipError_t launch_count_any(bool priv, bool filter, int r, yawhip_ctx *ctx, cons
                   : launch_count_r<W, false, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
 }
 
-// Sort every (patch, bin) segment by z (ties by original index, so the order is deterministic).
+// Sort every (patch, bin) segment by the key column (ties by original index, so the order is deterministic).
 // Returns the permutation; segments are independent, a few host threads share them.
-std::vector<int64_t> sort_segments_by_z(int64_t n, const double *z, const int64_t *offsets, int64_t nseg) {
+std::vector<int64_t> sort_segments_by_key(int64_t n, const double *z, const int64_t *offsets, int64_t nseg) {
     std::vector<int64_t> perm((size_t)n);
     std::iota(perm.begin(), perm.end(), (int64_t)0);
     std::atomic<int64_t> next{0};
@@ -805,7 +812,20 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
 int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
                           const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
                           yawhip_catalog **out) {
+    return yawhip_catalog_upload_axis(ctx, n, x, y, z, w, n_patches, n_bins_or_1, offsets, 2, out);
+}
+
+int yawhip_catalog_sort_axis(const yawhip_catalog *cat, int32_t *axis) {
+    if (!cat || !axis) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_sort_axis: NULL argument");
+    *axis = cat->axis;
+    return YAWHIP_OK;
+}
+
+int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+                               const double *w, int32_t n_patches, int32_t n_bins_or_1, const int64_t *offsets,
+                               int32_t sort_axis, yawhip_catalog **out) {
     if (!out) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: out is NULL");
+    if (sort_axis < 0 || sort_axis > 2) return fail(YAWHIP_ERR_INVALID, "sort_axis must be 0 (x), 1 (y) or 2 (z)");
     *out = nullptr;
     if (!ctx) return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: ctx is NULL");
     if (n < 0 || n_patches <= 0 || n_bins_or_1 <= 0 || !offsets || (n > 0 && (!x || !y || !z)))
@@ -821,15 +841,16 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
     c->n = n;
     c->n_patches = n_patches;
     c->nb = n_bins_or_1;
+    c->axis = sort_axis;
     c->h_off.assign(offsets, offsets + nseg + 1);
     for (int64_t i = 0; i < n && c->unit_norm; ++i) {
         const double n2 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
         if (!(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL)) c->unit_norm = false;
     }
-    // library-private order inside a segment: ascending z (enables the SWEEP windows)
+    // library-private order inside a segment: ascending along the sort axis (enables the SWEEP windows)
     std::vector<double> sx, sy, sz, sw;
     try {
-        const std::vector<int64_t> perm = sort_segments_by_z(n, z, offsets, nseg);
+        const std::vector<int64_t> perm = sort_segments_by_key(n, key_of(x, y, z, sort_axis), offsets, nseg);
         auto gather = [&](const double *src, std::vector<double> &dst) {
             dst.resize((size_t)n);
             for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = src[perm[(size_t)i]];
@@ -872,7 +893,7 @@ int yawhip_catalog_upload(yawhip_ctx *ctx, int64_t n, const double *x, const dou
         for (int64_t sgm = 0; sgm < nseg; ++sgm)
             for (int64_t i = offsets[sgm]; i < offsets[sgm + 1]; ++i) kk[(size_t)i] = (int32_t)(sgm % n_bins_or_1);
         {
-            const std::vector<int64_t> perm = sort_segments_by_z(n, z, poff.data(), n_patches);
+            const std::vector<int64_t> perm = sort_segments_by_key(n, key_of(x, y, z, sort_axis), poff.data(), n_patches);
             for (int64_t i = 0; i < n; ++i) {
                 const int64_t src = perm[(size_t)i];
                 sx[(size_t)i] = x[src]; sy[(size_t)i] = y[src]; sz[(size_t)i] = z[src];
@@ -961,6 +982,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // the FP32 pre-filter assumes unit vectors; anything else is evaluated pair by pair in FP64
     const bool unit = c1->unit_norm && c2->unit_norm;
     if (kernel == YAWHIP_KERNEL_FILTER && !unit) kernel = YAWHIP_KERNEL_EXACT;
+    // the window search compares the sorted coordinate of both sides: the axes must agree
+    if (kernel == YAWHIP_KERNEL_SWEEP && c1->axis != c2->axis) kernel = unit ? YAWHIP_KERNEL_FILTER : YAWHIP_KERNEL_EXACT;
     const bool sweep = kernel == YAWHIP_KERNEL_SWEEP;
     const bool filter = unit && kernel != YAWHIP_KERNEL_EXACT;
 
@@ -1070,7 +1093,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
         const unsigned bgrid = (unsigned)((n_pot + 255) / 256);
-        const CatView v1 = merged ? CatView{c1->mx, c1->my, c1->mz, c1->mw, c1->moff, 1} : view_of(c1);
+        const CatView v1 = merged ? CatView{c1->mx, c1->my, c1->mz, c1->mw, c1->moff, 1, key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->axis}
+                                  : view_of(c1);
         if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, v1, view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, merged ? 1 : n_bins, (int)tile,

@@ -33,24 +33,30 @@ def release() -> None:
     _contexts.clear()
 
 
-def device_catalog(layout, ctx=None) -> "_lib.DeviceCatalog":
+def device_catalog(layout, ctx=None, sort_axis: int = 2) -> "_lib.DeviceCatalog":
+    """Upload (once per context) and return the device copy of a layout. ``sort_axis`` is the
+    coordinate the library sorts segments by for its window culling; a copy made for another axis
+    is replaced."""
     ctx = ctx or get_context()
     dev = layout.device.get(id(ctx))
+    if dev is not None and dev.sort_axis != sort_axis:
+        dev.free()
+        dev = None
     if dev is None:
         dev = _lib.DeviceCatalog(ctx, layout.x, layout.y, layout.z, layout.w, layout.num_patches, layout.num_bins,
-                                 layout.offsets)
+                                 layout.offsets, sort_axis=sort_axis)
         layout.device[id(ctx)] = dev
     return dev
 
 
-def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None):
+def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None, sort_axis: int = 2):
     """Fine-bin pair counts for ``jobs`` (int[n,2]) -> (f64[n_jobs, B, E-1], CountStats).
 
     Unweighted catalogues are counted in int64 on the device and converted exactly
     (the reference's ``.astype(np.float64)``, trees.py:353)."""
     ctx = get_context()
-    d1 = device_catalog(layout1, ctx)
-    d2 = d1 if layout2 is layout1 else device_catalog(layout2, ctx)
+    d1 = device_catalog(layout1, ctx, sort_axis)
+    d2 = d1 if layout2 is layout1 else device_catalog(layout2, ctx, sort_axis)
     counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)
     fine = sums if sums is not None else counts.astype(np.float64)
     return fine, stats

@@ -88,6 +88,16 @@ def job_costs(layout1, layout2, jobs, thresholds, tile: int = 1024) -> np.ndarra
     return n1 * n2 * window + 1e3 * (n1 + n2)  # + per-object cost of touching the patches at all
 
 
+def best_sort_axis(center_xyz, num_records) -> int:
+    """Coordinate axis (0 = x, 1 = y, 2 = z) most perpendicular to the footprint's mean direction:
+    patches are widest along it, so the device's 1-d window culling removes the most pairs. A
+    footprint without a preferred direction (full sky) keeps z."""
+    mean = (center_xyz * num_records[:, np.newaxis]).sum(axis=0) / max(float(num_records.sum()), 1.0)
+    if np.linalg.norm(mean) < 0.2:
+        return 2
+    return int(np.argmin(np.abs(mean)))
+
+
 class PatchLinkage:
     """Which patch pairs can contain pairs of objects within the largest scale.
 
@@ -98,6 +108,7 @@ class PatchLinkage:
         self.config = config
         self.patch_links = patch_links
         self.last_stats = None
+        self.sort_axis = 2  # coordinate the device sorts by for its window culling (set by from_catalogs)
         # derived once per linkage (the configuration is immutable): thresholds and job tables
         self._plans = None
         self._thresholds = None
@@ -124,7 +135,9 @@ class PatchLinkage:
         for pid, center, radius in zip(patch_ids, centers, radii):
             linked = centers.distance(center).data < (radii + radius + max_angle)
             links[pid] = set(compress(patch_ids, linked))
-        return cls(config, links)
+        new = cls(config, links)
+        new.sort_axis = best_sort_axis(centers.to_3d(), np.asarray(ref_cat.get_num_records(), dtype=np.float64))
+        return new
 
     @property
     def num_total(self) -> int:
@@ -190,7 +203,7 @@ class PatchLinkage:
         mine = np.arange(len(jobs))
         if size > 1:
             mine = parallel.partition_jobs(job_costs(layout1, layout2, jobs, thresholds), size)[rank]
-        fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds)
+        fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis)
         self.last_stats = stats
 
         # dense [B, E-1, P, P] tensor; each slot is written by exactly one rank
