@@ -128,3 +128,39 @@ def run_twodflens_case():
     check_corrfuncs("auto", cfs, g, exact=lambda k: False)
     for cat in cats.values():
         cat.drop_layouts()
+
+
+def run_reference_example_case():
+    """The reference's own end-to-end known answer (tests/test_setups.py:155-172): bundled 2dFLenS
+    data (src/yaw/examples/*.pqt, copied as data files), default configuration in *physical* units
+    (100-1000 kpc, Planck15) -> crosscorrelate + autocorrelate -> n(z) = w_sp / sqrt(dz^2 w_ss)
+    must equal src/yaw/examples/estimate.{dat,smp} to 6 decimals (assert_array_almost_equal)."""
+    import os
+
+    import yet_another_wizz_amd as yaw
+    from conftest import GOLDEN
+    from yet_another_wizz_amd.redshifts import RedshiftData
+
+    d = os.path.join(GOLDEN, "reference_example")
+    kw = dict(ra_name="RA", dec_name="Dec", weight_name="wei", redshift_name="redshift", patch_name="patch")
+    data = os.path.join(d, "2dflens_kidss_data.pqt")
+    ref = yaw.Catalog.from_file(None, data, **kw)
+    unk = yaw.Catalog.from_file(None, data, **kw)
+    rnd = yaw.Catalog.from_file(None, os.path.join(d, "2dflens_kidss_rand_5x.pqt"), **kw)
+    assert ref.num_patches == 11 and sum(ref.get_num_records()) == 21875 and sum(rnd.get_num_records()) == 109375
+    config = yaw.Configuration.create(rmin=100, rmax=1000, zmin=0.15, zmax=0.7, num_bins=11)  # examples/__init__.py:271
+    (cross,) = yaw.crosscorrelate(config, ref, unk, ref_rand=rnd)     # create_example_data.py:23-26
+    (auto,) = yaw.autocorrelate(config, ref, rnd)                      # create_example_data.py:29
+    assert cross.rd is not None and cross.dr is None and cross.get_estimator().name == "DP"
+    assert auto.rr is not None and auto.get_estimator().name == "LS"
+    nz = RedshiftData.from_corrfuncs(cross, auto)                      # create_example_data.py:36
+    dat = np.loadtxt(os.path.join(d, "estimate.dat"))
+    smp = np.loadtxt(os.path.join(d, "estimate.smp"))
+    cov = np.loadtxt(os.path.join(d, "estimate.cov"))
+    np.testing.assert_array_almost_equal(np.column_stack([nz.binning.left, nz.binning.right]), dat[:, :2])
+    np.testing.assert_array_almost_equal(nz.data, dat[:, 2])           # 6 decimals, as the reference's test
+    np.testing.assert_array_almost_equal(nz.error, dat[:, 3])
+    np.testing.assert_array_almost_equal(nz.samples.T, smp[:, 2:])
+    np.testing.assert_array_almost_equal(nz.covariance, cov)
+    for cat in (ref, unk, rnd):
+        cat.drop_layouts()

@@ -18,6 +18,10 @@ def test_twodflens_vs_reference_on_gpu():
     helpers.run_twodflens_case()
 
 
+def test_reference_end_to_end_known_answer_on_gpu():
+    helpers.run_reference_example_case()
+
+
 def test_native_library_is_the_one_running():
     from yet_another_wizz_amd import _lib
 

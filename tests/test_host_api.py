@@ -24,6 +24,10 @@ def test_twodflens_vs_reference(oracle_engine):
     helpers.run_twodflens_case()
 
 
+def test_reference_end_to_end_known_answer(oracle_engine):
+    helpers.run_reference_example_case()
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: without a GPU the real engine must raise, never return numbers."""
     from yet_another_wizz_amd import _lib

@@ -23,6 +23,7 @@ from .corrdata import CorrData, SampledData
 from .corrfunc import CorrFunc
 from .measurements import PatchLinkage, autocorrelate, crosscorrelate
 from .paircounts import NormalisedCounts, PatchedCounts, PatchedSumWeights
+from .redshifts import RedshiftData
 
 __version__ = "0.1.0"
 
@@ -40,6 +41,7 @@ __all__ = [
     "PatchLinkage",
     "PatchedCounts",
     "PatchedSumWeights",
+    "RedshiftData",
     "SampledData",
     "autocorrelate",
     "crosscorrelate",
