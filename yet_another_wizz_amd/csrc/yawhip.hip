@@ -6,23 +6,24 @@
 // FMA -- the predicate scipy's KDTree.count_neighbors applies behind AngularTree.count
 // (src/yaw/catalog/trees.py:303-362).
 //
-// Design (wave64, no MFMA -- K=3 distances are not a contraction and bit parity forbids a dot-product rewrite):
+// Design (wave64, no MFMA -- K=3 distances are not a contraction and bit parity forbids replacing the
+// predicate by a dot-product form; DESIGN.md section 4 has the details and the measurements):
 //   * catalogues live in HBM as SoA float64 columns x,y,z,(w), sorted by (patch, z-bin) with a CSR
-//     offset table; every column load is a fully coalesced 512 B per wave;
-//   * inside a segment objects are kept sorted by their z coordinate (done once at upload; the ABI
-//     leaves the order inside a segment to the library);
-//   * work item = (job, bin, lane tile): a 256-thread workgroup keeps TILE = 256*R objects of the
-//     c2 segment in registers (R per lane) and streams a window of the c1 segment through LDS in
-//     256-object stages (register-staged double buffer), reading each streamed object as a wave-wide
-//     LDS broadcast. A builder kernel (k_build_items) turns the job table into item records; with
-//     the SWEEP path it binary-searches, per item, the z-window of the c1 segment that can hold a
-//     partner of the tile (|dz| <= sqrt(t_max)) and drops items whose window is empty;
-//   * per streamed object: 8 FP64 VALU ops + 1 compare per lane-object; a wave ballot of "s <= t_max"
-//     skips the histogram update for the >99.9 % of iterations without any pair inside the outer edge;
-//   * counters: per-lane private LDS histograms (no atomics in the loop), fixed-order tree reduction
-//     at the end of the item; unweighted results are added with 64-bit integer atomics (exact,
-//     order independent), weighted results go to a per-item slab that a second kernel sums in item
-//     order, so weighted sums are bit-reproducible run to run.
+//     offset table; inside a segment objects are sorted along one coordinate (z unless the caller picks
+//     another axis) -- done once at upload, the ABI leaves the order inside a segment to the library.
+//     A binned catalogue is additionally kept as one sorted run per patch with the bin id per object;
+//   * k_build_items turns the job table into work items (job, bin, lane tile) and, on the SWEEP path,
+//     binary-searches per item the window of the streamed segment that can hold a partner of the tile
+//     (|du| <= sqrt(t_max)), dropping items with an empty window;
+//   * k_count: a 256-thread workgroup keeps 256*R objects of the c2 segment in registers and streams
+//     the window of the c1 segment through LDS (register-staged double buffer, wave-wide broadcast
+//     reads). EXACT: 8 FP64 ops + compare per pair. FILTER/SWEEP: a conservative FP32 dot-product test
+//     first, exact FP64 only for its survivors. Per-lane private LDS histograms, fixed-order reduction,
+//     64-bit integer atomics (unweighted) or per-item slabs summed in item order (weighted);
+//   * k_count_merged: the cross-correlation fast path (binned x unbinned) -- one item streams one window
+//     of the merged run for all bins, float32 only on chip, survivors queued per wave and evaluated 64
+//     at a time from L2-hot float64 data.
+// No floating point atomics anywhere: weighted sums are bit-reproducible run to run.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (see yet_another_wizz_amd/build.py).
 
 #include <hip/hip_runtime.h>
