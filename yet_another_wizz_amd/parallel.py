@@ -30,8 +30,9 @@ def world() -> tuple[int, int]:
 
 
 def local_device_index() -> int:
-    """GPU of this process: LOCAL_RANK as set by ``python -m torch.distributed.run``."""
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    """GPU of this process: LOCAL_RANK as set by ``python -m torch.distributed.run``
+    (``YAW_AMD_DEVICE`` overrides it, e.g. to let several ranks share one GPU in a test)."""
+    return int(os.environ.get("YAW_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
 def partition_jobs(costs, num_parts: int) -> list:
