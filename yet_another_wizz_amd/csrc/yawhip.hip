@@ -379,25 +379,31 @@ struct MergedView {
     const int32_t *k;             // bin id per object
 };
 
-template <int R, bool WEIGHTED, bool NF1>
+// MERGED = false runs the same machinery on ordinary (job, bin, tile) items of the (patch, bin) layout
+// (autocorrelation counts): every streamed object then belongs to the item's bin.
+template <int R, bool WEIGHTED, bool NF1, bool MERGED>
 __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
-                                                     const float *__restrict__ dthr, double rwin, int64_t item_base,
-                                                     unsigned long long *__restrict__ out_counts,
+                                                     const float *__restrict__ dthr, const double *__restrict__ rwin_k,
+                                                     int64_t item_base, unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw);                                // [2][MSTAGE]
-    double *thr = reinterpret_cast<double *>(stagef + 2 * MSTAGE);                   // [n_bins][n_edges]
-    HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)n_bins * n_edges);         // [NHIST][n_bins*nf]
-    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * n_bins * (n_edges - 1));  // [n_bins]
-    unsigned int *candq = reinterpret_cast<unsigned int *>(dth + n_bins);            // [WG/64][64] survivor codes
+    double *thr = reinterpret_cast<double *>(stagef + 2 * MSTAGE);                   // [nkb][n_edges]
+    const int nkb_l = MERGED ? n_bins : 1;
+    HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)nkb_l * n_edges);          // [NHIST][nkb*nf]
+    float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * nkb_l * (n_edges - 1));  // [nkb]
+    unsigned int *candq = reinterpret_cast<unsigned int *>(dth + nkb_l);             // [WG/64][64] survivor codes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nf = n_edges - 1, nslots = n_bins * nf;
+    const int nf = n_edges - 1;
     const Item it = items[item_base + blockIdx.x];
-    const int job = it.slot;
+    const int kfix = MERGED ? 0 : it.slot % n_bins;  // the item's bin (ordinary items)
+    const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
+    const int nslots = nkb * nf;
+    const double rwin = rwin_k[kfix];
     const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
     const int64_t a0 = it.a0, a_end = it.a0 + it.na;
     // wave-contiguous assignment: wave w owns objects [w*64R, (w+1)*64R) of the z-sorted tile, so its
@@ -430,8 +436,8 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             wz_hi = -4.0f;
         }
     }
-    for (int e = tid; e < n_bins * n_edges; e += WG) thr[e] = t[e];
-    for (int e = tid; e < n_bins; e += WG) dth[e] = dthr[3 * e];
+    for (int e = tid; e < nkb * n_edges; e += WG) thr[e] = t[(int64_t)kfix * n_edges + e];
+    for (int e = tid; e < nkb; e += WG) dth[e] = dthr[3 * (kfix + e)];
     for (int e = tid; e < NHIST * nslots; e += WG) hist[e] = HistT(0);
     __syncthreads();
 
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
     auto fetch = [&](int64_t i) {  // float32 record of streamed object i; slots past the window never pass
         ObjF o{0.f, 0.f, 0.f, 2.0f};
-        if (i < b1) o = ObjF{(float)c1.x[i], (float)c1.y[i], (float)c1.z[i], dth[c1.k[i]]};
+        if (i < b1) o = ObjF{(float)c1.x[i], (float)c1.y[i], (float)c1.z[i], dth[MERGED ? c1.k[i] : 0]};
         return o;
     };
     if (tid < MSTAGE) stagef[tid] = fetch(b0 + tid);
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
                 const double zz = dz * dz;
                 const double sxy = xx + yy;
                 const double s = sxy + zz;
-                const int kb = c1.k[ib];
+                const int kb = MERGED ? c1.k[ib] : 0;
                 const double *tk = thr + kb * n_edges;
                 if (s > tk[0] && s <= tk[n_edges - 1]) {
                     if (NF1) {
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             partials[(int64_t)it.pot * nslots + idx] = v;
         } else {
             const unsigned int v = reinterpret_cast<unsigned int *>(hist)[idx];
-            if (v) atomicAdd(&out_counts[(int64_t)job * nslots + idx], (unsigned long long)v);
+            if (v) atomicAdd(&out_counts[(int64_t)it.slot * nslots + idx], (unsigned long long)v);
         }
     }
 }
@@ -1007,13 +1013,17 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     }
     const int64_t tile = (int64_t)WG * R;
 
-    // Cross-correlation fast path (k_count_merged): c1 binned, c2 unbinned, unit vectors, LDS permitting.
+    // Lean path (k_count_merged): z-window culling + FP32 pre-filter + queued exact evaluation. Its merged
+    // form (one item for all bins) serves c1 binned x c2 unbinned, i.e. every count of a cross-correlation.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
-    const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)n_bins * n_edges * sizeof(double) +
-                              (size_t)n_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)n_bins * sizeof(float) +
+    const bool lean = sweep && filter;
+    const bool merged = lean && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2;
+    const int lean_bins = merged ? n_bins : 1;
+    const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
+                              (size_t)lean_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
                               (size_t)WG * sizeof(unsigned int) + 16;
-    const bool merged = sweep && filter && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2 &&
-                        lds_merged <= (size_t)ctx->lds_limit;
+    if (lean && lds_merged > (size_t)ctx->lds_limit)
+        return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", lds_merged);
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
@@ -1112,46 +1122,55 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (run_weighted && sweep)  // dropped items leave their slab untouched
             HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
-    if (n_items > 0 && merged) {
-        const MergedView mv{c1->mx, c1->my, c1->mz, c1->mw, c1->mk};
-        auto launch_merged = [&](bool wgt) -> hipError_t {
+    if (n_items > 0 && lean) {
+        const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
+                                     : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
+        auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
                 const unsigned g = (unsigned)std::min(max_grid, n_items - base);
-#define YAW_LAUNCH_MERGED(RR, WW)                                                                                     \
+#define YAW_LAUNCH_LEAN(RR, WW, NN, MM)                                                                               \
     do {                                                                                                              \
-        auto kern = nf == 1 ? k_count_merged<RR, WW, true> : k_count_merged<RR, WW, false>;                          \
+        auto kern = k_count_merged<RR, WW, NN, MM>;                                                                   \
         if (lds_merged > 64 * 1024) {                                                                                 \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, view_of(c2), ctx->d_items.ptr, n_bins, \
-                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, rwin_max, base, ctx->d_counts.ptr,               \
+                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,          \
                            ctx->d_partials.ptr);                                                                      \
     } while (0)
+#define YAW_LAUNCH_LEAN_R(WW, NN, MM)                                                                                 \
+    do {                                                                                                              \
+        if (R == 1) YAW_LAUNCH_LEAN(1, WW, NN, MM); else if (R == 2) YAW_LAUNCH_LEAN(2, WW, NN, MM); else YAW_LAUNCH_LEAN(4, WW, NN, MM); \
+    } while (0)
+                const bool nf1 = nf == 1;
                 if (wgt) {
-                    if (R == 1) YAW_LAUNCH_MERGED(1, true); else if (R == 2) YAW_LAUNCH_MERGED(2, true); else YAW_LAUNCH_MERGED(4, true);
+                    if (nf1) { if (merged) YAW_LAUNCH_LEAN_R(true, true, true); else YAW_LAUNCH_LEAN_R(true, true, false); }
+                    else     { if (merged) YAW_LAUNCH_LEAN_R(true, false, true); else YAW_LAUNCH_LEAN_R(true, false, false); }
                 } else {
-                    if (R == 1) YAW_LAUNCH_MERGED(1, false); else if (R == 2) YAW_LAUNCH_MERGED(2, false); else YAW_LAUNCH_MERGED(4, false);
+                    if (nf1) { if (merged) YAW_LAUNCH_LEAN_R(false, true, true); else YAW_LAUNCH_LEAN_R(false, true, false); }
+                    else     { if (merged) YAW_LAUNCH_LEAN_R(false, false, true); else YAW_LAUNCH_LEAN_R(false, false, false); }
                 }
-#undef YAW_LAUNCH_MERGED
+#undef YAW_LAUNCH_LEAN_R
+#undef YAW_LAUNCH_LEAN
                 hipError_t el = hipGetLastError();
                 if (el != hipSuccess) return el;
             }
             return hipSuccess;
         };
         if (run_unweighted) {
-            HIP_TRY(launch_merged(false));
+            HIP_TRY(launch_lean(false));
             ++launches;
         }
         if (run_weighted) {
-            HIP_TRY(launch_merged(true));
+            HIP_TRY(launch_lean(true));
             ++launches;
             const int thr = 256;
-            const int64_t n_red = (int64_t)n_jobs * slab;
+            const int64_t n_red = n_pslots * slab;
             hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_red + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_jobs, (int)slab, ctx->d_sums.ptr);
+                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_pslots, (int)slab, ctx->d_sums.ptr);
             HIP_TRY(hipGetLastError());
             ++launches;
         }
