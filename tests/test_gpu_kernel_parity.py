@@ -315,3 +315,27 @@ def test_sort_axis_variants(ctx):
     assert np.array_equal(counts, exp) and st.kernel_used == _lib.KERNEL_FILTER and st.evaluated_pairs == st.candidate_pairs
     with pytest.raises(_lib.YawhipError, match="sort_axis"):
         _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=3)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_wide_angles_and_ragged_tiles(ctx, kernel):
+    """Separations beyond 90 degrees (the dot-product threshold of the pre-filter becomes negative) and
+    segment sizes that are no multiple of the tile: padded lanes must stay silent."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(123)
+    def sphere(n, nb):
+        ra = rng.uniform(0, 2 * np.pi, n); dec = np.arcsin(rng.uniform(-1, 1, n))
+        patch = rng.integers(0, 2, n); z = rng.uniform(0.1, 0.9, n)
+        return oracle.sort_catalog(ra, dec, z, None, patch, 2, np.linspace(0.1, 0.9, nb + 1) if nb > 1 else None, "right")
+    c1, c2 = sphere(777, 3), sphere(1301, 1)
+    jobs = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.int32)
+    lim = oracle.parse_ang_limits(np.deg2rad([5.0, 60.0]), np.deg2rad([60.0, 150.0]))
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (3, 1))
+    exp, _ = oracle.count_jobs(c1, c2, jobs, t)
+    counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), jobs, t, kernel=kernel)
+    assert np.array_equal(counts, exp) and exp.sum() > 0.5 * 777 * 1301 * 0.3
+    # and the self count of the binned catalogue (ordinary items)
+    exp, _ = oracle.count_jobs(c1, c1, jobs, t)
+    counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c1), jobs, t, kernel=kernel)
+    assert np.array_equal(counts, exp)

@@ -220,11 +220,11 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
         az[r] = ok ? c2.z[i] : PAD_COORD;
         aw[r] = (WEIGHTED && ok && c2.w) ? c2.w[i] : (ok ? 1.0 : 0.0);
     }
-    float fx[R], fy[R], fz[R];  // float32 images; a padded lane gets 0 -> dot = 0 < any threshold >= ~-1
+    float fx[R], fy[R], fz[R];  // float32 images; a padded lane gets NaN -> its dot product fails every comparison
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool ok = a0 + (int64_t)r * WG + tid < a_seg1;
-        fx[r] = ok ? (float)ax[r] : 0.f;
+        fx[r] = ok ? (float)ax[r] : __builtin_nanf("");
         fy[r] = ok ? (float)ay[r] : 0.f;
         fz[r] = ok ? (float)az[r] : 0.f;
     }
@@ -415,7 +415,8 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     for (int r = 0; r < R; ++r) {
         const int64_t i = wa0 + (int64_t)r * 64 + lane;
         const bool ok = i < a_end;
-        fx[r] = ok ? (float)c2.x[i] : 0.f;  // padded lane: dot = 0, below every threshold
+        fx[r] = ok ? (float)c2.x[i] : __builtin_nanf("");  // padded lane: dot = NaN fails every comparison (thresholds
+                                                            // are <= 0 for separations >= 90 degrees, so 0 would pass)
         fy[r] = ok ? (float)c2.y[i] : 0.f;
         fz[r] = ok ? (float)c2.z[i] : 0.f;
     }
