@@ -62,6 +62,31 @@ def angular_plans(config):
     ]
 
 
+def combine_all(plans, fine_bej) -> np.ndarray:
+    """``AngularBinPlan.combine`` for all bins at once: fine[B, E-1, J] -> [S, B, J]. Bins whose plans share
+    the edge count, the per-scale slices and the separation weights (always the case for angular
+    units) are handled in one vectorised pass."""
+    num_bins, _, num_jobs = fine_bej.shape
+    num_scales = plans[0].num_scales
+    out = np.empty((num_scales, num_bins, num_jobs), dtype=np.float64)
+    first = plans[0]
+    uniform = all(
+        p.num_edges == first.num_edges and p._slices == first._slices
+        and (p._scale_factor is None) == (first._scale_factor is None)
+        for p in plans
+    )
+    if uniform:
+        block = fine_bej[:, : first.num_edges - 1]
+        if first._scale_factor is not None:
+            block = block * np.stack([p._scale_factor for p in plans])[:, :, np.newaxis]
+        for s, (lo, hi) in enumerate(first._slices):
+            out[s] = block[:, lo:hi].sum(axis=1)
+        return out
+    for k, plan in enumerate(plans):
+        out[:, k] = plan.combine(fine_bej[k, : plan.num_edges - 1].T).T
+    return out
+
+
 def threshold_table(plans) -> np.ndarray:
     """f64[B, Emax]. Bins with fewer edges are padded by repeating their last threshold: the
     padded fine bins (t < s <= t) are empty by construction."""
@@ -206,23 +231,28 @@ class PatchLinkage:
         fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis)
         self.last_stats = stats
 
-        # dense [B, E-1, P, P] tensor; each slot is written by exactly one rank
-        dense = np.zeros((num_bins, num_fine, num_patches, num_patches), dtype=np.float64)
-        if len(mine):
-            dense[:, :, jobs[mine, 0], jobs[mine, 1]] = np.moveaxis(fine, 0, -1)
-        dense = parallel.allreduce_sum(dense)
-
-        # host epilogue, O(jobs * B * E): separation weights, per-scale recombination, halving of
-        # the doubly counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364)
-        scale_counts = [PatchedCounts.zeros(binning, num_patches, auto=auto) for _ in range(self.config.scales.num_scales)]
+        # fine[b, e, j]: fine-bin counts of every job. With several ranks each one fills its own slots of a
+        # zero-initialised dense [B, E-1, P, P] tensor and one sum all-reduce combines them (every slot is
+        # non-zero on exactly one rank, so the sum is exact and order independent).
         id1, id2 = jobs[:, 0], jobs[:, 1]
+        if size > 1:
+            dense = np.zeros((num_bins, num_fine, num_patches, num_patches), dtype=np.float64)
+            if len(mine):
+                dense[:, :, jobs[mine, 0], jobs[mine, 1]] = np.moveaxis(fine, 0, -1)
+            fine_bej = parallel.allreduce_sum(dense)[:, :, id1, id2]
+        else:
+            fine_bej = np.moveaxis(fine, 0, -1)
+
+        # host epilogue, O(jobs * B * E): separation weights, per-scale recombination, halving of the doubly
+        # counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364)
         halve = np.where(id1 == id2, 0.5, 1.0) if auto else None
-        for k, plan in enumerate(plans):
-            per_scale = plan.combine(dense[k, : plan.num_edges - 1][:, id1, id2].T)  # [n_jobs, E-1] -> [n_jobs, S]
-            if halve is not None:
-                per_scale = per_scale * halve[:, np.newaxis]
-            for s, container in enumerate(scale_counts):
-                container.counts[k, id1, id2] = per_scale[:, s]
+        num_scales = self.config.scales.num_scales
+        counts = np.zeros((num_scales, num_bins, num_patches, num_patches), dtype=np.float64)
+        per_scale = combine_all(plans, fine_bej)  # [S, B, n_jobs]
+        if halve is not None:
+            per_scale = per_scale * halve
+        counts[:, :, id1, id2] = per_scale
+        scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(num_scales)]
 
         sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
                                         auto=auto)
