@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, con
         if (keep) items[base + __popcll(mask & ((1ull << lane) - 1ull))] = it;
     } else if (pot < n_pot) {
         items[pot] = it;
+        if (pot == 0) counters[0] = (unsigned long long)n_pot;  // every potential item is kept
     }
     // evaluated pairs: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
                                               int n_edges, const double *__restrict__ t,
                                               const float *__restrict__ dthr, int64_t item_base,
                                               unsigned long long *__restrict__ out_counts,
-                                              double *__restrict__ partials) {
+                                              double *__restrict__ partials,
+                                              const unsigned long long *__restrict__ n_kept) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Obj *stage = reinterpret_cast<Obj *>(lds_raw);                                  // [2][STAGE]
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 
     const int tid = threadIdx.x;
     const int nf = n_edges - 1;
+    if ((unsigned long long)(item_base + blockIdx.x) >= *n_kept) return;  // grid = potential items; the builder kept fewer
     const Item it = items[item_base + blockIdx.x];
     const int slot = it.slot;
     const int k = slot % n_bins;
@@ -386,7 +389,8 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
                                                      int n_bins, int n_edges, const double *__restrict__ t,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
                                                      int64_t item_base, unsigned long long *__restrict__ out_counts,
-                                                     double *__restrict__ partials) {
+                                                     double *__restrict__ partials,
+                                                     const unsigned long long *__restrict__ n_kept) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1;
+    if ((unsigned long long)(item_base + blockIdx.x) >= *n_kept) return;  // grid = potential items; the builder kept fewer
     const Item it = items[item_base + blockIdx.x];
     const int kfix = MERGED ? 0 : it.slot % n_bins;  // the item's bin (ordinary items)
     const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
@@ -673,7 +678,7 @@ hipError_t launch_count(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_
         const int64_t g = std::min(max_grid, n_items - base);
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WG), lds_bytes, ctx->stream, view_of(c1), view_of(c2),
                            ctx->d_items.ptr, n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, base, ctx->d_counts.ptr,
-                           ctx->d_partials.ptr);
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1117,9 +1122,10 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                ctx->d_items.ptr, ctx->d_ctr.ptr);
         HIP_TRY(hipGetLastError());
         ++launches;
+        // The count kernels are launched over all potential items and return at once for indices beyond the
+        // number the builder kept (device counter): no host round trip between the two kernels.
         HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));  // the grid of the count kernel = surviving items
-        n_items = sweep ? (int64_t)ctr[0] : n_pot;
+        n_items = n_pot;
         if (run_weighted && sweep)  // dropped items leave their slab untouched
             HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
@@ -1140,7 +1146,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, view_of(c2), ctx->d_items.ptr, n_bins, \
                            n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,          \
-                           ctx->d_partials.ptr);                                                                      \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
 #define YAW_LAUNCH_LEAN_R(WW, NN, MM)                                                                                 \
     do {                                                                                                              \
@@ -1215,7 +1221,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->candidate_pairs = cand;
         stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
         stats->algorithmic_bytes = abytes;
-        stats->n_workgroups = n_items;
+        stats->n_workgroups = n_pot > 0 ? (int64_t)ctr[0] : 0;
         stats->n_launches = launches;
         stats->kernel_used = kernel;
         stats->kernel_ms = ms;
