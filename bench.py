@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--tile-r", type=int, default=0, help="objects per lane (0 = library default)")
     ap.add_argument("--debug-no-hits", action="store_true", help="diagnostics: time the pre-filter only (wrong counts)")
+    ap.add_argument("--strip-micro", type=int, default=None, help="strip grid spacing in 1e-6 chord units (0 = no strips)")
     return ap.parse_args()
 
 
@@ -144,6 +145,8 @@ def main():
         engine.get_context().set_option("tile_r", args.tile_r)
     if args.debug_no_hits:
         engine.get_context().set_option("debug_no_hits", 1)
+    if args.strip_micro is not None:
+        engine.get_context().set_option("strip_width_micro", args.strip_micro)
     t_setup = time.perf_counter()
     config, ref, unk = make_catalogs(args)
     ref.build_trees(config.binning.edges, closed=config.binning.closed)

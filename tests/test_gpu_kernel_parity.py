@@ -298,6 +298,16 @@ def test_sort_axis_variants(ctx):
     t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (B, 1))
     exp, _ = oracle.count_jobs(c1, c2, jobs, t)
     evaluated = {}
+    ctx.set_option("strip_width_micro", 0)  # culling along the sort axis alone
+    try:
+        _sort_axis_checks(ctx, c1, c2, jobs, t, exp, evaluated, P, B)
+    finally:
+        ctx.set_option("strip_width_micro", 20000)
+
+
+def _sort_axis_checks(ctx, c1, c2, jobs, t, exp, evaluated, P, B):
+    from yet_another_wizz_amd import _lib
+
     for axis in (0, 1, 2):
         d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=axis)
         d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=axis)
@@ -339,3 +349,48 @@ def test_wide_angles_and_ragged_tiles(ctx, kernel):
     exp, _ = oracle.count_jobs(c1, c1, jobs, t)
     counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c1), jobs, t, kernel=kernel)
     assert np.array_equal(counts, exp)
+
+
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+def test_strip_widths(ctx, weights):
+    """The cross-correlation path cuts patches into strips of a global grid and pairs only strips
+    within reach. Any grid spacing (also none, and different spacings on the two sides, which
+    disables the strip pairing) gives the same fine-bin counts. (That strips reduce the evaluated
+    pairs at survey sizes is checked in test_gpu_scale_properties.py.)"""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(1234)
+    P, B = 5, 3
+    c1 = _random_catalog(rng, 30000, P, B, weights[0] == "w", dense_box=6.0)
+    c2 = _random_catalog(rng, 40000, P, 1, weights[1] == "w", dense_box=6.0)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    t = []
+    for k in range(B):
+        lim = oracle.parse_ang_limits(np.array([1.0]) * np.pi / 10800, np.array([12.0 + 3 * k]) * np.pi / 10800)
+        t.append(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)))
+    t = np.stack(t)
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    assert exp_c.sum() > 10000
+    evaluated = {}
+    try:
+        for micro in (0, 1000, 3500, 20000, 300000):
+            ctx.set_option("strip_width_micro", micro)
+            d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+            for tile_r in (0, 1, 4):
+                ctx.set_option("tile_r", tile_r)
+                counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="sweep", want_counts=True, want_sums=True)
+                assert st.kernel_used == _lib.KERNEL_SWEEP
+                assert np.array_equal(counts, exp_c), (micro, tile_r)
+                if weights == "ww":
+                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+            evaluated[micro] = st.evaluated_pairs
+            if micro == 20000:  # catalogue with another grid: ordinary (job, bin) items
+                ctx.set_option("strip_width_micro", 5000)
+                d2b = _upload(ctx, c2)
+                counts, _, _ = _lib.count_pairs(ctx, d1, d2b, jobs, t, kernel="sweep", want_counts=True)
+                assert np.array_equal(counts, exp_c)
+        with pytest.raises(_lib.YawhipError, match="strip_width_micro"):
+            ctx.set_option("strip_width_micro", 10)
+    finally:
+        ctx.set_option("strip_width_micro", 20000)
+        ctx.set_option("tile_r", 0)

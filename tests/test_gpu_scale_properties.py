@@ -56,6 +56,28 @@ def test_three_code_paths_agree_at_1m(setup):
     assert np.array_equal(f_exact, s["fine"][::5])
 
 
+def test_strips_cull_but_do_not_change_counts(setup):
+    """Fresh uploads without the strip grid and with a finer one: same counts, fewer evaluated pairs."""
+    from yet_another_wizz_amd import _lib, engine
+
+    s = setup
+    ctx = engine.get_context()
+    evaluated = {20000: s["stats"].evaluated_pairs}
+    try:
+        for micro in (0, 5000):
+            ctx.set_option("strip_width_micro", micro)
+            devs = [_lib.DeviceCatalog(ctx, l.x, l.y, l.z, l.w, l.num_patches, l.num_bins, l.offsets, sort_axis=2)
+                    for l in (s["lref"], s["lunk"])]
+            counts, _, st = _lib.count_pairs(ctx, devs[0], devs[1], s["jobs"], s["t"], kernel="sweep")
+            assert np.array_equal(counts.astype(np.float64), s["fine"]), micro
+            evaluated[micro] = st.evaluated_pairs
+            for d in devs:
+                d.free()
+    finally:
+        ctx.set_option("strip_width_micro", 20000)
+    assert evaluated[20000] < 0.6 * evaluated[0] and evaluated[5000] < 0.6 * evaluated[0]
+
+
 def test_role_swap_symmetry(setup):
     """count(ref_p, unk_q) == count(unk_q, ref_p): lanes <-> stream, binned <-> unbinned."""
     from yet_another_wizz_amd import engine

@@ -174,6 +174,60 @@ __global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Item builder of the strip path. A sub-slot = (run of c1, run of c2, output slot): the pair of
+// (patch, strip) runs of one job that are close enough to hold pairs. One thread per potential item
+// (sub-slot, lane tile of the c2 run); window search and compaction as in k_build_items<true>.
+// sub[4*i] = {run in c1, run in c2, output slot, unused}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_items_sub(const double *__restrict__ key1, const int64_t *__restrict__ off1,
+                                                         const double *__restrict__ key2, const int64_t *__restrict__ off2,
+                                                         const int32_t *__restrict__ sub, const int64_t *__restrict__ prefix,
+                                                         int n_sub, int tile, double rwin, int64_t n_pot,
+                                                         Item *__restrict__ items, unsigned long long *__restrict__ counters) {
+    const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    Item it{};
+    unsigned long long work = 0;
+    if (pot < n_pot) {
+        int lo = 0, hi = n_sub;  // sub-slot = largest s with prefix[s] <= pot
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= pot) lo = mid; else hi = mid;
+        }
+        const int r1 = sub[4 * lo], r2 = sub[4 * lo + 1], oslot = sub[4 * lo + 2];
+        int64_t b0 = off1[r1], b1 = off1[r1 + 1];
+        const int64_t a_seg1 = off2[r2 + 1];
+        const int64_t a0 = off2[r2] + (pot - prefix[lo]) * (int64_t)tile;
+        const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
+        const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
+        int64_t l = b0, h = b1;  // first index with key >= wlo
+        while (l < h) {
+            const int64_t m = (l + h) >> 1;
+            if (key1[m] < wlo) l = m + 1; else h = m;
+        }
+        const int64_t first = l;
+        h = b1;  // first index with key > whi
+        while (l < h) {
+            const int64_t m = (l + h) >> 1;
+            if (key1[m] <= whi) l = m + 1; else h = m;
+        }
+        b0 = first;
+        b1 = l;
+        keep = b1 > b0;
+        it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = oslot; it.pot = (int32_t)pot;
+        work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == 0 && mask) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0, 64);
+    if (keep) items[base + __popcll(mask & ((1ull << lane) - 1ull))] = it;
+    for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
+    if ((threadIdx.x & 63) == 0 && work) atomicAdd(&counters[1], work);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pair count kernel.
 //   R         objects per lane (lane tile = 256*R objects of the c2 segment)
 //   WEIGHTED  accumulate w_a*w_b in float64 (else count in uint32)
@@ -626,10 +680,13 @@ struct yawhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int tile_r = 0;          // 0 = auto
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
+    double strip_width = 0.02;  // strip grid of newly uploaded catalogues (chord units, ~69 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
     DevBuf<int32_t> d_jobs;
     DevBuf<int64_t> d_prefix;
+    DevBuf<int64_t> d_prefix_out;   // strip path: first potential item of every output slot
+    DevBuf<int32_t> d_sub;          // strip path: sub-slot table, 4 ints per entry
     DevBuf<double> d_t;
     DevBuf<float> d_dthr;
     DevBuf<double> d_rwin;
@@ -650,11 +707,18 @@ struct yawhip_catalog {
     int64_t device_bytes = 0;
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
     int axis = 2;           // coordinate the segments are sorted by (0 = x, 1 = y, 2 = z)
-    // merged layout of a binned catalogue: all bins of a patch in one z-sorted run (+ bin id per object)
+    // strip layout (every catalogue): each patch cut into strips of a global grid along a second axis
+    // ("virtual patches"); inside a (patch, strip) run all redshift bins together, sorted along the sort
+    // axis, with the bin id per object for a binned catalogue. The cross-correlation fast path pairs only
+    // strips that are at most sqrt(t_max) apart.
     double *mx = nullptr, *my = nullptr, *mz = nullptr, *mw = nullptr;
     int32_t *mk = nullptr;
-    int64_t *moff = nullptr;  // [P+1]
-    std::vector<int64_t> h_moff;
+    int64_t *moff = nullptr;          // [V+1] offsets of the (patch, strip) runs
+    std::vector<int64_t> h_moff;      // same on the host
+    std::vector<int64_t> h_vbase;     // [P+1] first run of every patch
+    std::vector<int64_t> h_slo;       // [P]   global strip index of a patch's first run
+    double strip_width = 0.0;         // grid spacing (chord units); 0 = one run per patch
+    int strip_axis = 0;
 };
 
 namespace {
@@ -728,6 +792,26 @@ std::vector<int64_t> sort_segments_by_key(int64_t n, const double *z, const int6
     return perm;
 }
 
+// Same for an index vector that is already grouped into runs (strip layout).
+void sort_runs_by_key(std::vector<int64_t> &idx, const double *z, const int64_t *offsets, int64_t nseg) {
+    std::atomic<int64_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t lo = next.fetch_add(64);
+            if (lo >= nseg) break;
+            for (int64_t sgm = lo; sgm < std::min(lo + 64, nseg); ++sgm)
+                std::sort(idx.begin() + offsets[sgm], idx.begin() + offsets[sgm + 1],
+                          [z](int64_t a, int64_t b) { return z[a] < z[b] || (z[a] == z[b] && a < b); });
+        }
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = idx.size() < (1u << 16) ? 1u : std::min(std::max(hw, 1u), 16u);
+    std::vector<std::thread> pool;
+    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
+    worker();
+    for (auto &th : pool) th.join();
+}
+
 inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
     const int kk = c->nb == 1 ? 0 : k;
     const int64_t i = (int64_t)patch * c->nb + kk;
@@ -786,6 +870,8 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_jobs.release();
     ctx->d_prefix.release();
+    ctx->d_prefix_out.release();
+    ctx->d_sub.release();
     ctx->d_t.release();
     ctx->d_dthr.release();
     ctx->d_rwin.release();
@@ -807,6 +893,12 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(YAWHIP_ERR_INVALID, "tile_r must be 0 (auto), 1, 2 or 4");
         ctx->tile_r = (int)value;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "strip_width_micro")) {  // strip grid spacing in units of 1e-6 (0 = off)
+        if (value != 0 && (value < 1000 || value > 2000000))
+            return fail(YAWHIP_ERR_INVALID, "strip_width_micro must be 0 (off) or in [1e3, 2e6]");
+        ctx->strip_width = (double)value * 1e-6;
         return YAWHIP_OK;
     }
     if (!strcmp(key, "debug_no_hits")) {
@@ -898,44 +990,87 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
                     hipGetErrorString(e));
     }
     c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
-    if (n_bins_or_1 > 1 && n > 0) {
-        // second, merged layout for the cross-correlation fast path: per patch, all bins in one z-sorted run
-        std::vector<int64_t> poff((size_t)n_patches + 1);
-        for (int p = 0; p <= n_patches; ++p) poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
-        std::vector<int32_t> kk((size_t)n), sk((size_t)n);
-        for (int64_t sgm = 0; sgm < nseg; ++sgm)
-            for (int64_t i = offsets[sgm]; i < offsets[sgm + 1]; ++i) kk[(size_t)i] = (int32_t)(sgm % n_bins_or_1);
-        {
-            const std::vector<int64_t> perm = sort_segments_by_key(n, key_of(x, y, z, sort_axis), poff.data(), n_patches);
+    if (c->unit_norm && n > 0) {
+        // second, strip layout for the cross-correlation fast path: runs of (patch, strip), all bins together,
+        // sorted along the sort axis inside a run. Strips are cells of a global grid along strip_axis, so that
+        // runs of different catalogues can be paired by their grid index alone.
+        const double width = ctx->strip_width;
+        const int saxis = (sort_axis + 2) % 3;  // z -> y, y -> x, x -> z
+        const double *v = key_of(x, y, z, saxis);
+        auto strip_of = [width, v](int64_t i) -> int64_t { return width > 0.0 ? (int64_t)std::floor((v[i] + 1.0) / width) : 0; };
+        std::vector<int64_t> vbase((size_t)n_patches + 1, 0), slo((size_t)n_patches, 0), voff;
+        std::vector<int32_t> kk, sk;
+        try {
+            for (int p = 0; p < n_patches; ++p) {
+                const int64_t i0 = offsets[(int64_t)p * n_bins_or_1], i1 = offsets[(int64_t)(p + 1) * n_bins_or_1];
+                int64_t lo = 0, hi = -1;
+                for (int64_t i = i0; i < i1; ++i) {
+                    const int64_t g = strip_of(i);
+                    if (hi < lo) lo = hi = g;
+                    lo = std::min(lo, g);
+                    hi = std::max(hi, g);
+                }
+                slo[(size_t)p] = lo;
+                vbase[(size_t)p + 1] = vbase[(size_t)p] + (hi - lo + 1);  // an empty patch has no runs
+            }
+            const int64_t n_runs = vbase[(size_t)n_patches];
+            voff.assign((size_t)n_runs + 1, 0);
+            std::vector<int64_t> run((size_t)n);
+            for (int p = 0; p < n_patches; ++p)
+                for (int64_t i = offsets[(int64_t)p * n_bins_or_1]; i < offsets[(int64_t)(p + 1) * n_bins_or_1]; ++i) {
+                    run[(size_t)i] = vbase[(size_t)p] + strip_of(i) - slo[(size_t)p];
+                    ++voff[(size_t)run[(size_t)i] + 1];
+                }
+            for (int64_t r = 0; r < n_runs; ++r) voff[(size_t)r + 1] += voff[(size_t)r];
+            // bucket by run (stable), then sort every run along the sort axis
+            std::vector<int64_t> fill(voff.begin(), voff.end() - 1), bucket((size_t)n);
+            for (int64_t i = 0; i < n; ++i) bucket[(size_t)fill[(size_t)run[(size_t)i]]++] = i;
+            if (n_bins_or_1 > 1) {
+                kk.resize((size_t)n);
+                sk.resize((size_t)n);
+                for (int64_t sgm = 0; sgm < nseg; ++sgm)
+                    for (int64_t i = offsets[sgm]; i < offsets[sgm + 1]; ++i) kk[(size_t)i] = (int32_t)(sgm % n_bins_or_1);
+            }
+            sort_runs_by_key(bucket, key_of(x, y, z, sort_axis), voff.data(), n_runs);
             for (int64_t i = 0; i < n; ++i) {
-                const int64_t src = perm[(size_t)i];
+                const int64_t src = bucket[(size_t)i];
                 sx[(size_t)i] = x[src]; sy[(size_t)i] = y[src]; sz[(size_t)i] = z[src];
                 if (w) sw[(size_t)i] = w[src];
-                sk[(size_t)i] = kk[(size_t)src];
+                if (n_bins_or_1 > 1) sk[(size_t)i] = kk[(size_t)src];
             }
+        } catch (const std::exception &ex) {
+            yawhip_catalog_free(c);
+            return fail(YAWHIP_ERR_OOM, "host-side strip layout failed: %s", ex.what());
         }
+        const int64_t n_runs = vbase[(size_t)n_patches];
         e = hipMalloc(reinterpret_cast<void **>(&c->mx), col);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->my), col);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mz), col);
         if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->mw), col);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mk), (size_t)n * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->moff), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess && n_bins_or_1 > 1) e = hipMalloc(reinterpret_cast<void **>(&c->mk), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->moff), (size_t)(n_runs + 1) * sizeof(int64_t));
         if (e == hipSuccess) e = hipMemcpyAsync(c->mx, sx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->my, sy.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(c->mz, sz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && w)
             e = hipMemcpyAsync(c->mw, sw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->mk, sk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && n_bins_or_1 > 1)
+            e = hipMemcpyAsync(c->mk, sk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(c->moff, poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(c->moff, voff.data(), (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             yawhip_catalog_free(c);
-            return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (merged layout) failed: %s",
+            return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (strip layout) failed: %s",
                         hipGetErrorString(e));
         }
-        c->h_moff = poff;
-        c->device_bytes += (int64_t)col * (w ? 4 : 3) + n * (int64_t)sizeof(int32_t) + (n_patches + 1) * (int64_t)sizeof(int64_t);
+        c->h_moff = std::move(voff);
+        c->h_vbase = std::move(vbase);
+        c->h_slo = std::move(slo);
+        c->strip_width = width;
+        c->strip_axis = saxis;
+        c->device_bytes += (int64_t)col * (w ? 4 : 3) + (n_bins_or_1 > 1 ? n * (int64_t)sizeof(int32_t) : 0) +
+                           (n_runs + 1) * (int64_t)sizeof(int64_t);
     }
     *out = c;
     return YAWHIP_OK;
@@ -1010,20 +1145,32 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
 
     // tile size: objects per lane. Larger tiles amortise the streamed-object read; small segments
     // prefer small tiles so that padded lanes do not dominate.
+    // Lean path (k_count_merged): z-window culling + FP32 pre-filter + queued exact evaluation. Its merged
+    // form (one item for all bins, strip layouts on both sides) serves c1 binned x c2 unbinned, i.e. every
+    // count of a cross-correlation.
+    const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
+    const bool lean = sweep && filter;
+    const bool merged = lean && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c2->mx != nullptr && c1 != c2 &&
+                        c1->strip_width == c2->strip_width && c1->strip_axis == c2->strip_axis;
     int R = ctx->tile_r;
     if (R == 0) {
         int64_t max_seg = 0;
-        for (int j = 0; j < n_jobs; ++j)
-            for (int k = 0; k < (c2->nb == 1 ? 1 : n_bins); ++k) max_seg = std::max(max_seg, seg_len(c2, jobs[2 * j + 1], k));
+        if (merged) {  // lanes hold runs of the strip layout
+            std::vector<char> seen((size_t)c2->n_patches, 0);
+            for (int j = 0; j < n_jobs; ++j) {
+                const int q = jobs[2 * j + 1];
+                if (seen[(size_t)q]) continue;
+                seen[(size_t)q] = 1;
+                for (int64_t r = c2->h_vbase[(size_t)q]; r < c2->h_vbase[(size_t)q + 1]; ++r)
+                    max_seg = std::max(max_seg, c2->h_moff[(size_t)r + 1] - c2->h_moff[(size_t)r]);
+            }
+        } else {
+            for (int j = 0; j < n_jobs; ++j)
+                for (int k = 0; k < (c2->nb == 1 ? 1 : n_bins); ++k) max_seg = std::max(max_seg, seg_len(c2, jobs[2 * j + 1], k));
+        }
         R = max_seg >= 8 * WG * 4 ? 4 : (max_seg >= 4 * WG * 2 ? 2 : 1);
     }
     const int64_t tile = (int64_t)WG * R;
-
-    // Lean path (k_count_merged): z-window culling + FP32 pre-filter + queued exact evaluation. Its merged
-    // form (one item for all bins) serves c1 binned x c2 unbinned, i.e. every count of a cross-correlation.
-    const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
-    const bool lean = sweep && filter;
-    const bool merged = lean && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c1 != c2;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
                               (size_t)lean_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
@@ -1033,12 +1180,49 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
-    const int64_t n_pslots = merged ? (int64_t)n_jobs : n_slots;
-    std::vector<int64_t> prefix((size_t)n_pslots + 1);
+    // merged path: a job (p, q) is split into sub-slots (run of p, run of q) of strips close enough to hold
+    // pairs; slot = sub-slot for the builder, the items carry the job as their output slot.
+    double rwin_max = 0.0;  // widest window half width over the bins
+    for (int k = 0; k < n_bins; ++k)
+        rwin_max = std::max(rwin_max, std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15);
+    std::vector<int64_t> prefix, prefix_out;
+    std::vector<int32_t> sub;
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
+    if (merged) {
+        const double width = c1->strip_width;
+        // |dv| <= rwin_max  ->  grid indices differ by at most floor(rwin_max / width) + 1
+        const int64_t reach = width > 0.0 ? (int64_t)std::floor(rwin_max / width + 1e-6) + 1 : 0;
+        prefix_out.resize((size_t)n_jobs + 1);
+        for (int j = 0; j < n_jobs; ++j) {
+            const int p = jobs[2 * j], q = jobs[2 * j + 1];
+            prefix_out[(size_t)j] = n_items;
+            const int64_t base1 = c1->h_vbase[(size_t)p], cnt1 = c1->h_vbase[(size_t)p + 1] - base1, lo1 = c1->h_slo[(size_t)p];
+            const int64_t base2 = c2->h_vbase[(size_t)q], cnt2 = c2->h_vbase[(size_t)q + 1] - base2, lo2 = c2->h_slo[(size_t)q];
+            for (int64_t s2 = 0; s2 < cnt2; ++s2) {
+                const int64_t r2 = base2 + s2, n2 = c2->h_moff[(size_t)r2 + 1] - c2->h_moff[(size_t)r2];
+                if (n2 == 0) continue;
+                const int64_t g2 = lo2 + s2;
+                const int64_t s1_lo = std::max<int64_t>(g2 - reach - lo1, 0), s1_hi = std::min<int64_t>(g2 + reach - lo1, cnt1 - 1);
+                for (int64_t s1 = s1_lo; s1 <= s1_hi; ++s1) {
+                    const int64_t r1 = base1 + s1;
+                    if (c1->h_moff[(size_t)r1 + 1] == c1->h_moff[(size_t)r1]) continue;
+                    sub.push_back((int32_t)r1);
+                    sub.push_back((int32_t)r2);
+                    sub.push_back((int32_t)j);
+                    sub.push_back(0);
+                    prefix.push_back(n_items);
+                    n_items += (n2 + tile - 1) / tile;
+                }
+            }
+        }
+        prefix_out[(size_t)n_jobs] = n_items;
+        prefix.push_back(n_items);
+    } else {
+        prefix.resize((size_t)n_slots + 1);
+    }
+    const int64_t n_pslots = merged ? (int64_t)prefix.size() - 1 : n_slots;
     for (int j = 0; j < n_jobs; ++j) {
-        int64_t n1_all = 0;
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
             if (!merged) prefix[(size_t)j * n_bins + k] = n_items;
@@ -1046,18 +1230,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                 if (!merged) n_items += (n2 + tile - 1) / tile;
                 cand += n1 * n2;
             }
-            n1_all += n1;
-        }
-        if (merged) {
-            const int64_t n2 = seg_len(c2, jobs[2 * j + 1], 0);
-            prefix[(size_t)j] = n_items;
-            if (n1_all > 0 && n2 > 0) n_items += (n2 + tile - 1) / tile;
         }
         // algorithmic bytes of a job = every object of the two patches once (Bobj * (N1 + N2))
         for (int k = 0; k < c1->nb; ++k) abytes += seg_len(c1, jobs[2 * j], k) * obj_bytes1;
         for (int k = 0; k < c2->nb; ++k) abytes += seg_len(c2, jobs[2 * j + 1], k) * obj_bytes2;
     }
-    prefix[(size_t)n_pslots] = n_items;
+    if (!merged) prefix[(size_t)n_pslots] = n_items;
     const int64_t slab = merged ? (int64_t)n_bins * nf : nf;  // float64 values per item of the weighted slab
 
     const bool want_counts = fine_counts != nullptr;
@@ -1083,6 +1261,14 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
                            ctx->stream));
+    if (merged) {
+        HIP_TRY(ctx->d_prefix_out.reserve((size_t)n_jobs + 1));
+        HIP_TRY(ctx->d_sub.reserve(std::max<size_t>(sub.size(), 4)));
+        HIP_TRY(hipMemcpyAsync(ctx->d_prefix_out.ptr, prefix_out.data(), sizeof(int64_t) * ((size_t)n_jobs + 1),
+                               hipMemcpyHostToDevice, ctx->stream));
+        if (!sub.empty())
+            HIP_TRY(hipMemcpyAsync(ctx->d_sub.ptr, sub.data(), sizeof(int32_t) * sub.size(), hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * 3 * n_bins, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
@@ -1092,7 +1278,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
-    double rwin_max = 0.0;  // widest z-window half width over the bins
     const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
     unsigned long long ctr[2] = {0ull, 0ull};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
@@ -1102,22 +1287,22 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(ctx->d_ctr.reserve(2));
         HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
         std::vector<double> rwin((size_t)n_bins);
-        for (int k = 0; k < n_bins; ++k) {
-            rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
-            rwin_max = std::max(rwin_max, rwin[(size_t)k]);
-        }
+        for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
         if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
         const unsigned bgrid = (unsigned)((n_pot + 255) / 256);
-        const CatView v1 = merged ? CatView{c1->mx, c1->my, c1->mz, c1->mw, c1->moff, 1, key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->axis}
-                                  : view_of(c1);
-        if (sweep)
-            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, v1, view_of(c2),
-                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, merged ? 1 : n_bins, (int)tile,
+        if (merged)
+            hipLaunchKernelGGL(k_build_items_sub, dim3(bgrid), dim3(256), 0, ctx->stream,
+                               key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->moff, key_of(c2->mx, c2->my, c2->mz, c2->axis),
+                               c2->moff, ctx->d_sub.ptr, ctx->d_prefix.ptr, (int)n_pslots, (int)tile, rwin_max, n_pot,
+                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+        else if (sweep)
+            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
+                               ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
                                ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr);
         else
-            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, v1, view_of(c2),
+            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr);
         HIP_TRY(hipGetLastError());
@@ -1132,6 +1317,9 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (n_items > 0 && lean) {
         const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
                                      : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
+        const CatView lanes = merged ? CatView{c2->mx, c2->my, c2->mz, c2->mw, c2->moff, 1,
+                                               key_of(c2->mx, c2->my, c2->mz, c2->axis), c2->axis}
+                                     : view_of(c2);
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
@@ -1144,7 +1332,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, view_of(c2), ctx->d_items.ptr, n_bins, \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, lanes, ctx->d_items.ptr, n_bins,      \
                            n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,          \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
@@ -1175,9 +1363,11 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             HIP_TRY(launch_lean(true));
             ++launches;
             const int thr = 256;
-            const int64_t n_red = n_pslots * slab;
+            const int64_t n_oslots = merged ? (int64_t)n_jobs : n_slots;  // slabs are reduced per output slot
+            const int64_t n_red = n_oslots * slab;
             hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_red + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_pslots, (int)slab, ctx->d_sums.ptr);
+                               ctx->d_partials.ptr, merged ? ctx->d_prefix_out.ptr : ctx->d_prefix.ptr, (int)n_oslots,
+                               (int)slab, ctx->d_sums.ptr);
             HIP_TRY(hipGetLastError());
             ++launches;
         }
