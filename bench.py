@@ -146,7 +146,7 @@ def main():
     if args.debug_no_hits:
         engine.get_context().set_option("debug_no_hits", 1)
     if args.strip_micro is not None:
-        engine.get_context().set_option("strip_width_micro", args.strip_micro)
+        engine.forced_strip_micro = args.strip_micro
     t_setup = time.perf_counter()
     config, ref, unk = make_catalogs(args)
     ref.build_trees(config.binning.edges, closed=config.binning.closed)

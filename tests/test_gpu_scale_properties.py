@@ -57,25 +57,23 @@ def test_three_code_paths_agree_at_1m(setup):
 
 
 def test_strips_cull_but_do_not_change_counts(setup):
-    """Fresh uploads without the strip grid and with a finer one: same counts, fewer evaluated pairs."""
+    """Fresh uploads without the strip grid and with other spacings: same counts, fewer evaluated pairs."""
     from yet_another_wizz_amd import _lib, engine
 
     s = setup
     ctx = engine.get_context()
-    evaluated = {20000: s["stats"].evaluated_pairs}
-    try:
-        for micro in (0, 5000):
-            ctx.set_option("strip_width_micro", micro)
-            devs = [_lib.DeviceCatalog(ctx, l.x, l.y, l.z, l.w, l.num_patches, l.num_bins, l.offsets, sort_axis=2)
-                    for l in (s["lref"], s["lunk"])]
-            counts, _, st = _lib.count_pairs(ctx, devs[0], devs[1], s["jobs"], s["t"], kernel="sweep")
-            assert np.array_equal(counts.astype(np.float64), s["fine"]), micro
-            evaluated[micro] = st.evaluated_pairs
-            for d in devs:
-                d.free()
-    finally:
-        ctx.set_option("strip_width_micro", 20000)
-    assert evaluated[20000] < 0.6 * evaluated[0] and evaluated[5000] < 0.6 * evaluated[0]
+    evaluated = {"auto": s["stats"].evaluated_pairs}
+    for micro in (0, 2000, 20000):
+        devs = [_lib.DeviceCatalog(ctx, l.x, l.y, l.z, l.w, l.num_patches, l.num_bins, l.offsets, sort_axis=2,
+                                   strip_micro=micro) for l in (s["lref"], s["lunk"])]
+        counts, _, st = _lib.count_pairs(ctx, devs[0], devs[1], s["jobs"], s["t"], kernel="sweep")
+        assert np.array_equal(counts.astype(np.float64), s["fine"]), micro
+        evaluated[micro] = st.evaluated_pairs
+        for d in devs:
+            d.free()
+    assert engine.strip_micro_for(s["t"]) == 4400  # 1.5 x chord of 10 arcmin
+    assert max(evaluated["auto"], evaluated[2000], evaluated[20000]) < 0.6 * evaluated[0]
+    assert evaluated["auto"] < evaluated[20000]
 
 
 def test_role_swap_symmetry(setup):

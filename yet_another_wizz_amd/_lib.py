@@ -14,6 +14,7 @@ import numpy as np
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libyawhip.so")
 
+DEFAULT_STRIP_MICRO = 5000  # the library's default strip grid spacing, in 1e-6 chord units
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_FILTER, KERNEL_SWEEP = 0, 1, 2, 3
 KERNEL_IDS = {"auto": KERNEL_AUTO, "exact": KERNEL_EXACT, "filter": KERNEL_FILTER, "sweep": KERNEL_SWEEP}
 
@@ -140,9 +141,12 @@ class Context:
         self._h = _vp()
         _check(load_library().yawhip_ctx_create(int(device), ctypes.byref(self._h)), "yawhip_ctx_create")
         self.device = int(device)
+        self.strip_micro = DEFAULT_STRIP_MICRO
 
     def set_option(self, key: str, value: int) -> None:
         _check(load_library().yawhip_ctx_set_option(self._h, key.encode(), int(value)), "yawhip_ctx_set_option")
+        if key == "strip_width_micro":
+            self.strip_micro = int(value)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
@@ -159,7 +163,10 @@ class Context:
 class DeviceCatalog:
     """SoA catalogue resident in HBM, sorted by (patch, bin). ``yawhip_catalog``."""
 
-    def __init__(self, ctx: Context, x, y, z, w, n_patches: int, n_bins_or_1: int, offsets, sort_axis: int = 2):
+    def __init__(self, ctx: Context, x, y, z, w, n_patches: int, n_bins_or_1: int, offsets, sort_axis: int = 2,
+                 strip_micro: int | None = None):
+        """``strip_micro``: spacing of the strip grid of the cross-correlation layout in 1e-6 chord
+        units (0 = no strips, None = whatever the context is set to)."""
         x, y, z, w = _f64(x), _f64(y), _f64(z), _f64(w)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n = len(x)
@@ -171,6 +178,10 @@ class DeviceCatalog:
         self.n, self.n_patches, self.n_bins = n, int(n_patches), int(n_bins_or_1)
         self.weighted = w is not None
         self._h = _vp()
+        if strip_micro is not None:
+            ctx.set_option("strip_width_micro", int(strip_micro))
+            ctx.strip_micro = int(strip_micro)
+        self.strip_micro = ctx.strip_micro
         _check(
             load_library().yawhip_catalog_upload_axis(
                 ctx._h, n, _ptr(x, _dp), _ptr(y, _dp), _ptr(z, _dp), _ptr(w, _dp), self.n_patches, self.n_bins,

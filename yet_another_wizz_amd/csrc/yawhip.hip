@@ -48,10 +48,15 @@ namespace {
 constexpr int WG = 256;      // threads per workgroup = 4 waves of 64
 constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 #ifndef YAW_MSTAGE
-#define YAW_MSTAGE 128
+#define YAW_MSTAGE 64
 #endif
+#ifndef YAW_MWG
+#define YAW_MWG 64
+#endif
+constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
+constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
 thread_local std::string g_last_error;
@@ -436,24 +441,33 @@ struct MergedView {
     const int32_t *k;             // bin id per object
 };
 
-// MERGED = false runs the same machinery on ordinary (job, bin, tile) items of the (patch, bin) layout
-// (autocorrelation counts): every streamed object then belongs to the item's bin.
-template <int R, bool WEIGHTED, bool NF1, bool MERGED>
-__global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, const Item *__restrict__ items,
+// MODE 1: the cross-correlation path described above (c2 unbinned).
+// MODE 2: both sides binned (every count of an autocorrelation, RR/RD of a cross-correlation): the lane
+//         objects carry a bin id too and a pair must agree in it. The streamed object's bin id travels
+//         in the low 6 bits of its pre-filter threshold (set on the host, rounding stays conservative), so
+//         the loop pays one integer compare per pair and the LDS record stays 16 bytes.
+// MODE 0: the same machinery on ordinary (job, bin, tile) items of the (patch, bin) layout, for catalogues
+//         without a common strip grid: every streamed object then belongs to the item's bin.
+constexpr int BIN_BITS = 6, BIN_MASK = (1 << BIN_BITS) - 1;
+template <int R, bool WEIGHTED, bool NF1, int MODE>
+__global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2, const int32_t *__restrict__ lane_k,
+                                                     const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
                                                      int64_t item_base, unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials,
                                                      const unsigned long long *__restrict__ n_kept) {
+    constexpr bool MERGED = MODE != 0;
+    constexpr bool LB = MODE == 2;  // lanes carry bin ids
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
-    constexpr int NHIST = WEIGHTED ? WG / 64 : 1;
+    constexpr int NHIST = WEIGHTED ? MWG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     ObjF *stagef = reinterpret_cast<ObjF *>(lds_raw);                                // [2][MSTAGE]
     double *thr = reinterpret_cast<double *>(stagef + 2 * MSTAGE);                   // [nkb][n_edges]
     const int nkb_l = MERGED ? n_bins : 1;
     HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)nkb_l * n_edges);          // [NHIST][nkb*nf]
     float *dth = reinterpret_cast<float *>(hist + (size_t)NHIST * nkb_l * (n_edges - 1));  // [nkb]
-    unsigned int *candq = reinterpret_cast<unsigned int *>(dth + nkb_l);             // [WG/64][64] survivor codes
+    unsigned int *candq = reinterpret_cast<unsigned int *>(dth + nkb_l);             // [MWG/64][64] survivor codes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1;
@@ -470,10 +484,12 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
     const int64_t wa0 = a0 + (int64_t)wave * (64 * R);
 
     float fx[R], fy[R], fz[R];
+    int kl[R];  // bin of the lane objects (MODE 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = wa0 + (int64_t)r * 64 + lane;
         const bool ok = i < a_end;
+        kl[r] = (LB && ok) ? lane_k[i] : -1;
         fx[r] = ok ? (float)c2.x[i] : __builtin_nanf("");  // padded lane: dot = NaN fails every comparison (thresholds
                                                             // are <= 0 for separations >= 90 degrees, so 0 would pass)
         fy[r] = ok ? (float)c2.y[i] : 0.f;
@@ -496,9 +512,9 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             wz_hi = -4.0f;
         }
     }
-    for (int e = tid; e < nkb * n_edges; e += WG) thr[e] = t[(int64_t)kfix * n_edges + e];
-    for (int e = tid; e < nkb; e += WG) dth[e] = dthr[3 * (kfix + e)];
-    for (int e = tid; e < NHIST * nslots; e += WG) hist[e] = HistT(0);
+    for (int e = tid; e < nkb * n_edges; e += MWG) thr[e] = t[(int64_t)kfix * n_edges + e];
+    for (int e = tid; e < nkb; e += MWG) dth[e] = dthr[3 * (kfix + e)];
+    for (int e = tid; e < NHIST * nslots; e += MWG) hist[e] = HistT(0);
     __syncthreads();
 
     const int64_t nb_total = b1 - b0;
@@ -508,16 +524,21 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         if (i < b1) o = ObjF{(float)c1.x[i], (float)c1.y[i], (float)c1.z[i], dth[MERGED ? c1.k[i] : 0]};
         return o;
     };
-    if (tid < MSTAGE) stagef[tid] = fetch(b0 + tid);
+    constexpr int NPF = (MSTAGE + MWG - 1) / MWG;  // stage slots a thread fills
+#pragma unroll
+    for (int f = 0; f < NPF; ++f)
+        if (f * MWG + tid < MSTAGE) stagef[f * MWG + tid] = fetch(b0 + f * MWG + tid);
     __syncthreads();
 
     int qn = 0;  // entries in this wave's survivor queue (wave-uniform)
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
         const int64_t sb0 = b0 + (int64_t)st * MSTAGE;  // global index of stage slot 0
-        ObjF nxt{};
+        ObjF nxt[NPF];
         const bool have_next = st + 1 < nstages;
-        if (have_next && tid < MSTAGE) nxt = fetch(sb0 + MSTAGE + tid);
+#pragma unroll
+        for (int f = 0; f < NPF; ++f)
+            if (have_next && f * MWG + tid < MSTAGE) nxt[f] = fetch(sb0 + MSTAGE + f * MWG + tid);
         const int64_t left = nb_total - (int64_t)st * MSTAGE;
         const int n = left < MSTAGE ? (int)left : MSTAGE;
         const ObjF *curf = stagef + cb * MSTAGE;
@@ -569,9 +590,10 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
         };
         // Owner lanes of the survivors of stage slot i push their code on the wave's queue.
         auto enqueue = [&](int i, const float (&d)[R], float dmin) {
+            const int kb = __float_as_int(dmin) & BIN_MASK;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool pass = d[r] >= dmin;
+                const bool pass = d[r] >= dmin && (!LB || kl[r] == kb);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                 if (m == 0ull) continue;  // uniform
                 const int cnt = __popcll(m);
@@ -603,14 +625,24 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             const ObjF n0 = curf[ip], n1 = curf[ip + 1];
             float d0[R], d1[R];
             float best0 = -2.f, best1 = -2.f;
+            bool p0 = false, p1 = false;
+            const int kb0 = __float_as_int(c0.pad) & BIN_MASK, kb1 = __float_as_int(c1r.pad) & BIN_MASK;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 d0[r] = __builtin_fmaf(fz[r], c0.z, __builtin_fmaf(fy[r], c0.y, fx[r] * c0.x));
                 d1[r] = __builtin_fmaf(fz[r], c1r.z, __builtin_fmaf(fy[r], c1r.y, fx[r] * c1r.x));
-                best0 = fmaxf(best0, d0[r]);
-                best1 = fmaxf(best1, d1[r]);
+                if (LB) {
+                    p0 |= (d0[r] >= c0.pad) & (kl[r] == kb0);
+                    p1 |= (d1[r] >= c1r.pad) & (kl[r] == kb1);
+                } else {
+                    best0 = fmaxf(best0, d0[r]);
+                    best1 = fmaxf(best1, d1[r]);
+                }
             }
-            const bool p0 = best0 >= c0.pad, p1 = best1 >= c1r.pad;
+            if (!LB) {
+                p0 = best0 >= c0.pad;
+                p1 = best1 >= c1r.pad;
+            }
             if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {
                 if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
                 if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
@@ -619,11 +651,13 @@ __global__ __launch_bounds__(WG) void k_count_merged(MergedView c1, CatView c2, 
             c1r = n1;
         }
         drain();  // codes refer to this stage's slots
-        if (have_next && tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + tid] = nxt;
+#pragma unroll
+        for (int f = 0; f < NPF; ++f)
+            if (have_next && f * MWG + tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + f * MWG + tid] = nxt[f];
         __syncthreads();
     }
 
-    for (int idx = tid; idx < nslots; idx += WG) {
+    for (int idx = tid; idx < nslots; idx += MWG) {
         if (WEIGHTED) {
             double v = 0.0;
             for (int wv = 0; wv < NHIST; ++wv) v += reinterpret_cast<double *>(hist)[wv * nslots + idx];
@@ -679,14 +713,23 @@ struct yawhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int tile_r = 0;          // 0 = auto
+    int binned_strips = 0;   // 1: binned x binned counts use the strip layout too (k_count_merged MODE 2)
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
-    double strip_width = 0.02;  // strip grid of newly uploaded catalogues (chord units, ~69 arcmin); 0 = no strips
+    double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
     DevBuf<int32_t> d_jobs;
     DevBuf<int64_t> d_prefix;
     DevBuf<int64_t> d_prefix_out;   // strip path: first potential item of every output slot
     DevBuf<int32_t> d_sub;          // strip path: sub-slot table, 4 ints per entry
+    // the sub-slot tables of the last strip-path call stay on the device; a repeated call (DD, DR, ... of
+    // one measurement share the job list) reuses them
+    struct {
+        bool valid = false;
+        uint64_t serial1 = 0, serial2 = 0, jobs_hash = 0;
+        int n_jobs = 0;
+        int64_t reach = 0, tile = 0, n_items = 0, n_sub = 0;
+    } sub_cache;
     DevBuf<double> d_t;
     DevBuf<float> d_dthr;
     DevBuf<double> d_rwin;
@@ -705,6 +748,7 @@ struct yawhip_catalog {
     int64_t *off = nullptr;
     std::vector<int64_t> h_off;
     int64_t device_bytes = 0;
+    uint64_t serial = 0;    // unique per upload (keys the sub-slot cache)
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
     int axis = 2;           // coordinate the segments are sorted by (0 = x, 1 = y, 2 = z)
     // strip layout (every catalogue): each patch cut into strips of a global grid along a second axis
@@ -901,6 +945,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->strip_width = (double)value * 1e-6;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "binned_strips")) {
+        ctx->binned_strips = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "debug_no_hits")) {
         ctx->debug_no_hits = value != 0;
         return YAWHIP_OK;
@@ -942,6 +990,8 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     HIP_TRY(hipSetDevice(ctx->device));
     yawhip_catalog *c = new (std::nothrow) yawhip_catalog();
     if (!c) return fail(YAWHIP_ERR_OOM, "host allocation failed");
+    static std::atomic<uint64_t> next_serial{1};
+    c->serial = next_serial.fetch_add(1);
     c->ctx = ctx;
     c->n = n;
     c->n_patches = n_patches;
@@ -1150,31 +1200,36 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // count of a cross-correlation.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
     const bool lean = sweep && filter;
-    const bool merged = lean && c1->nb > 1 && c2->nb == 1 && c1->mx != nullptr && c2->mx != nullptr && c1 != c2 &&
-                        c1->strip_width == c2->strip_width && c1->strip_axis == c2->strip_axis;
+    double rwin_max = 0.0;  // widest window half width over the bins
+    for (int k = 0; k < n_bins; ++k)
+        rwin_max = std::max(rwin_max, std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15);
+    // strip pairing pays while a run has few partner runs; for separations far beyond the grid spacing the
+    // ordinary (patch, bin) layout is used instead
+    const bool strips = lean && c1->mx != nullptr && c2->mx != nullptr && c1->strip_width == c2->strip_width &&
+                        c1->strip_axis == c2->strip_axis &&
+                        (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
+    // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items
+    const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1
+                     : (ctx->binned_strips && c1->nb > 1 && c2->nb > 1 && n_bins <= BIN_MASK + 1) ? 2 : 0;
+    const bool merged = mode != 0;
     int R = ctx->tile_r;
     if (R == 0) {
         int64_t max_seg = 0;
-        if (merged) {  // lanes hold runs of the strip layout
-            std::vector<char> seen((size_t)c2->n_patches, 0);
-            for (int j = 0; j < n_jobs; ++j) {
-                const int q = jobs[2 * j + 1];
-                if (seen[(size_t)q]) continue;
-                seen[(size_t)q] = 1;
-                for (int64_t r = c2->h_vbase[(size_t)q]; r < c2->h_vbase[(size_t)q + 1]; ++r)
-                    max_seg = std::max(max_seg, c2->h_moff[(size_t)r + 1] - c2->h_moff[(size_t)r]);
-            }
+        if (merged) {  // lanes hold runs of the strip layout: their typical (mean) length decides
+            const int64_t n_runs = c2->h_vbase[(size_t)c2->n_patches];
+            max_seg = c2->n / std::max<int64_t>(n_runs, 1);
         } else {
             for (int j = 0; j < n_jobs; ++j)
                 for (int k = 0; k < (c2->nb == 1 ? 1 : n_bins); ++k) max_seg = std::max(max_seg, seg_len(c2, jobs[2 * j + 1], k));
         }
-        R = max_seg >= 8 * WG * 4 ? 4 : (max_seg >= 4 * WG * 2 ? 2 : 1);
+        const int wg = lean ? MWG : WG;
+        R = max_seg >= 8 * wg * 4 ? 4 : (max_seg >= 4 * wg * 2 ? 2 : 1);
     }
-    const int64_t tile = (int64_t)WG * R;
+    const int64_t tile = (int64_t)(lean ? MWG : WG) * R;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
-                              (size_t)lean_bins * nf * (weighted_any ? 8 * (WG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
-                              (size_t)WG * sizeof(unsigned int) + 16;
+                              (size_t)lean_bins * nf * (weighted_any ? 8 * (MWG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
+                              (size_t)MWG * sizeof(unsigned int) + 16;
     if (lean && lds_merged > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", lds_merged);
 
@@ -1182,46 +1237,60 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
     // merged path: a job (p, q) is split into sub-slots (run of p, run of q) of strips close enough to hold
     // pairs; slot = sub-slot for the builder, the items carry the job as their output slot.
-    double rwin_max = 0.0;  // widest window half width over the bins
-    for (int k = 0; k < n_bins; ++k)
-        rwin_max = std::max(rwin_max, std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15);
     std::vector<int64_t> prefix, prefix_out;
     std::vector<int32_t> sub;
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
+    bool tables_cached = false;
+    int64_t n_sub = 0;
     if (merged) {
         const double width = c1->strip_width;
         // |dv| <= rwin_max  ->  grid indices differ by at most floor(rwin_max / width) + 1
         const int64_t reach = width > 0.0 ? (int64_t)std::floor(rwin_max / width + 1e-6) + 1 : 0;
-        prefix_out.resize((size_t)n_jobs + 1);
-        for (int j = 0; j < n_jobs; ++j) {
-            const int p = jobs[2 * j], q = jobs[2 * j + 1];
-            prefix_out[(size_t)j] = n_items;
-            const int64_t base1 = c1->h_vbase[(size_t)p], cnt1 = c1->h_vbase[(size_t)p + 1] - base1, lo1 = c1->h_slo[(size_t)p];
-            const int64_t base2 = c2->h_vbase[(size_t)q], cnt2 = c2->h_vbase[(size_t)q + 1] - base2, lo2 = c2->h_slo[(size_t)q];
-            for (int64_t s2 = 0; s2 < cnt2; ++s2) {
-                const int64_t r2 = base2 + s2, n2 = c2->h_moff[(size_t)r2 + 1] - c2->h_moff[(size_t)r2];
-                if (n2 == 0) continue;
-                const int64_t g2 = lo2 + s2;
-                const int64_t s1_lo = std::max<int64_t>(g2 - reach - lo1, 0), s1_hi = std::min<int64_t>(g2 + reach - lo1, cnt1 - 1);
-                for (int64_t s1 = s1_lo; s1 <= s1_hi; ++s1) {
-                    const int64_t r1 = base1 + s1;
-                    if (c1->h_moff[(size_t)r1 + 1] == c1->h_moff[(size_t)r1]) continue;
-                    sub.push_back((int32_t)r1);
-                    sub.push_back((int32_t)r2);
-                    sub.push_back((int32_t)j);
-                    sub.push_back(0);
-                    prefix.push_back(n_items);
-                    n_items += (n2 + tile - 1) / tile;
+        uint64_t h = 1469598103934665603ull;  // FNV-1a of the job list
+        for (int i = 0; i < 2 * n_jobs; ++i) h = (h ^ (uint64_t)(uint32_t)jobs[i]) * 1099511628211ull;
+        auto &sc = ctx->sub_cache;
+        if (sc.valid && sc.serial1 == c1->serial && sc.serial2 == c2->serial && sc.jobs_hash == h && sc.n_jobs == n_jobs &&
+            sc.reach == reach && sc.tile == tile) {
+            tables_cached = true;
+            n_items = sc.n_items;
+            n_sub = sc.n_sub;
+        } else {
+            sc.valid = false;
+            prefix_out.resize((size_t)n_jobs + 1);
+            for (int j = 0; j < n_jobs; ++j) {
+                const int p = jobs[2 * j], q = jobs[2 * j + 1];
+                prefix_out[(size_t)j] = n_items;
+                const int64_t base1 = c1->h_vbase[(size_t)p], cnt1 = c1->h_vbase[(size_t)p + 1] - base1, lo1 = c1->h_slo[(size_t)p];
+                const int64_t base2 = c2->h_vbase[(size_t)q], cnt2 = c2->h_vbase[(size_t)q + 1] - base2, lo2 = c2->h_slo[(size_t)q];
+                for (int64_t s2 = 0; s2 < cnt2; ++s2) {
+                    const int64_t r2 = base2 + s2, n2 = c2->h_moff[(size_t)r2 + 1] - c2->h_moff[(size_t)r2];
+                    if (n2 == 0) continue;
+                    const int64_t g2 = lo2 + s2;
+                    const int64_t s1_lo = std::max<int64_t>(g2 - reach - lo1, 0), s1_hi = std::min<int64_t>(g2 + reach - lo1, cnt1 - 1);
+                    for (int64_t s1 = s1_lo; s1 <= s1_hi; ++s1) {
+                        const int64_t r1 = base1 + s1;
+                        if (c1->h_moff[(size_t)r1 + 1] == c1->h_moff[(size_t)r1]) continue;
+                        sub.push_back((int32_t)r1);
+                        sub.push_back((int32_t)r2);
+                        sub.push_back((int32_t)j);
+                        sub.push_back(0);
+                        prefix.push_back(n_items);
+                        n_items += (n2 + tile - 1) / tile;
+                    }
                 }
             }
+            prefix_out[(size_t)n_jobs] = n_items;
+            prefix.push_back(n_items);
+            n_sub = (int64_t)prefix.size() - 1;
+            sc.serial1 = c1->serial; sc.serial2 = c2->serial; sc.jobs_hash = h; sc.n_jobs = n_jobs;
+            sc.reach = reach; sc.tile = tile; sc.n_items = n_items; sc.n_sub = n_sub;
         }
-        prefix_out[(size_t)n_jobs] = n_items;
-        prefix.push_back(n_items);
     } else {
+        ctx->sub_cache.valid = false;  // d_prefix is about to be overwritten
         prefix.resize((size_t)n_slots + 1);
     }
-    const int64_t n_pslots = merged ? (int64_t)prefix.size() - 1 : n_slots;
+    const int64_t n_pslots = merged ? n_sub : n_slots;
     for (int j = 0; j < n_jobs; ++j) {
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
@@ -1251,7 +1320,17 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     auto round_down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -4.0f); return f; };
     for (int k = 0; k < n_bins; ++k) {
         const double thi = t[(size_t)k * n_edges + n_edges - 1];
-        dthr[(size_t)3 * k] = ctx->debug_no_hits ? 2.0f : round_down(1.0 - 0.5 * thi - FILTER_GUARD);
+        float thr32 = ctx->debug_no_hits ? 2.0f : round_down(1.0 - 0.5 * thi - FILTER_GUARD);
+        if (mode == 2) {
+            // bin id in the low mantissa bits; the value may only move down (keeps the filter conservative)
+            if (!(thr32 >= 1e-30f)) thr32 = std::min(thr32, -1e-30f);
+            uint32_t bits;
+            memcpy(&bits, &thr32, sizeof bits);
+            bits = thr32 > 0.f ? ((bits - (BIN_MASK + 1)) & ~(uint32_t)BIN_MASK) : ((bits + BIN_MASK + 1) & ~(uint32_t)BIN_MASK);
+            bits |= (uint32_t)k;
+            memcpy(&thr32, &bits, sizeof bits);
+        }
+        dthr[(size_t)3 * k] = thr32;
         dthr[(size_t)3 * k + 1] = 0.f;  // reserved
         dthr[(size_t)3 * k + 2] = 0.f;
     }
@@ -1259,9 +1338,10 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
-                           ctx->stream));
-    if (merged) {
+    if (!tables_cached)
+        HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
+                               ctx->stream));
+    if (merged && !tables_cached) {
         HIP_TRY(ctx->d_prefix_out.reserve((size_t)n_jobs + 1));
         HIP_TRY(ctx->d_sub.reserve(std::max<size_t>(sub.size(), 4)));
         HIP_TRY(hipMemcpyAsync(ctx->d_prefix_out.ptr, prefix_out.data(), sizeof(int64_t) * ((size_t)n_jobs + 1),
@@ -1320,6 +1400,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         const CatView lanes = merged ? CatView{c2->mx, c2->my, c2->mz, c2->mw, c2->moff, 1,
                                                key_of(c2->mx, c2->my, c2->mz, c2->axis), c2->axis}
                                      : view_of(c2);
+        const int32_t *lane_k = mode == 2 ? c2->mk : nullptr;
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
@@ -1332,22 +1413,25 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(WG), lds_merged, ctx->stream, mv, lanes, ctx->d_items.ptr, n_bins,      \
-                           n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,          \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(MWG), lds_merged, ctx->stream, mv, lanes, lane_k, ctx->d_items.ptr,    \
+                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,  \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
 #define YAW_LAUNCH_LEAN_R(WW, NN, MM)                                                                                 \
     do {                                                                                                              \
         if (R == 1) YAW_LAUNCH_LEAN(1, WW, NN, MM); else if (R == 2) YAW_LAUNCH_LEAN(2, WW, NN, MM); else YAW_LAUNCH_LEAN(4, WW, NN, MM); \
     } while (0)
+#define YAW_LAUNCH_LEAN_M(WW, NN)                                                                                     \
+    do {                                                                                                              \
+        if (mode == 1) YAW_LAUNCH_LEAN_R(WW, NN, 1); else if (mode == 2) YAW_LAUNCH_LEAN_R(WW, NN, 2); else YAW_LAUNCH_LEAN_R(WW, NN, 0); \
+    } while (0)
                 const bool nf1 = nf == 1;
                 if (wgt) {
-                    if (nf1) { if (merged) YAW_LAUNCH_LEAN_R(true, true, true); else YAW_LAUNCH_LEAN_R(true, true, false); }
-                    else     { if (merged) YAW_LAUNCH_LEAN_R(true, false, true); else YAW_LAUNCH_LEAN_R(true, false, false); }
+                    if (nf1) YAW_LAUNCH_LEAN_M(true, true); else YAW_LAUNCH_LEAN_M(true, false);
                 } else {
-                    if (nf1) { if (merged) YAW_LAUNCH_LEAN_R(false, true, true); else YAW_LAUNCH_LEAN_R(false, true, false); }
-                    else     { if (merged) YAW_LAUNCH_LEAN_R(false, false, true); else YAW_LAUNCH_LEAN_R(false, false, false); }
+                    if (nf1) YAW_LAUNCH_LEAN_M(false, true); else YAW_LAUNCH_LEAN_M(false, false);
                 }
+#undef YAW_LAUNCH_LEAN_M
 #undef YAW_LAUNCH_LEAN_R
 #undef YAW_LAUNCH_LEAN
                 hipError_t el = hipGetLastError();
@@ -1405,6 +1489,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (want_sums)
         HIP_TRY(hipMemcpyAsync(fine_sums, ctx->d_sums.ptr, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (merged) ctx->sub_cache.valid = true;  // tables are on the device now
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
