@@ -436,6 +436,7 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 //               (stream order, r, lane) => bit-reproducible sums.
 // One item covers all B bins, so the c2 tile is read once per job instead of once per (job, bin).
 // ------------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct MergedView {
     const double *x, *y, *z, *w;  // w may be null
     const int32_t *k;             // bin id per object
@@ -483,62 +484,96 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
     // own z-window is narrower than the workgroup's
     const int64_t wa0 = a0 + (int64_t)wave * (64 * R);
 
+    // Everything the item needs from global memory is requested here, back to back, before the first use:
+    // lane objects, the key range of the wave, the first stage of the stream, thresholds (one memory latency).
+    const int64_t nb_total = b1 - b0;
+    const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
+    constexpr int NPF = (MSTAGE + MWG - 1) / MWG;  // stage slots a thread fills
+    struct Raw { double x, y, z; int k; bool in; };
+    auto fetch_raw = [&](int64_t i) {  // streamed object i (clamped into the window: unconditional loads)
+        Raw o;
+        o.in = i < b1;
+        const int64_t ic = o.in ? i : b0;
+        o.x = c1.x[ic]; o.y = c1.y[ic]; o.z = c1.z[ic];
+        o.k = MERGED ? c1.k[ic] : 0;
+        return o;
+    };
+    auto finish = [&](const Raw &o) {  // float32 record; slots past the window get a threshold nothing passes
+        return ObjF{(float)o.x, (float)o.y, (float)o.z, o.in ? dth[o.k] : 2.0f};
+    };
+    double lx[R], ly[R], lz[R];
+    int lk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t i = wa0 + (int64_t)r * 64 + lane;
+        const int64_t ic = i < a_end ? i : a0;  // padded lanes read a valid object
+        lx[r] = c2.x[ic]; ly[r] = c2.y[ic]; lz[r] = c2.z[ic];
+        lk[r] = LB ? lane_k[ic] : 0;
+    }
+    int64_t wa1 = wa0 + 64 * R;
+    if (wa1 > a_end) wa1 = a_end;
+    const bool wave_has = wa0 < wa1;
+    const double key_lo = c2.key[wave_has ? wa0 : a0], key_hi = c2.key[wave_has ? wa1 - 1 : a0];
+    Raw first[NPF];
+#pragma unroll
+    for (int f = 0; f < NPF; ++f) first[f] = fetch_raw(b0 + f * MWG + tid);
+    // threshold tables: the first MWG entries travel with the batch above (all of them in the standard
+    // 30 bins x 2 edges case), the rest in ordinary loops
+    const bool has_t0 = tid < nkb * n_edges, has_d0 = tid < nkb;
+    const double t0 = t[(int64_t)kfix * n_edges + (has_t0 ? tid : 0)];
+    const float d0 = dthr[3 * (kfix + (has_d0 ? tid : 0))];
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_t0) thr[tid] = t0;
+    if (has_d0) dth[tid] = d0;
+    for (int e = tid + MWG; e < nkb * n_edges; e += MWG) thr[e] = t[(int64_t)kfix * n_edges + e];
+    for (int e = tid + MWG; e < nkb; e += MWG) dth[e] = dthr[3 * (kfix + e)];
+    for (int e = tid; e < NHIST * nslots; e += MWG) hist[e] = HistT(0);
+    __syncthreads();
+
     float fx[R], fy[R], fz[R];
     int kl[R];  // bin of the lane objects (MODE 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t i = wa0 + (int64_t)r * 64 + lane;
-        const bool ok = i < a_end;
-        kl[r] = (LB && ok) ? lane_k[i] : -1;
-        fx[r] = ok ? (float)c2.x[i] : __builtin_nanf("");  // padded lane: dot = NaN fails every comparison (thresholds
-                                                            // are <= 0 for separations >= 90 degrees, so 0 would pass)
-        fy[r] = ok ? (float)c2.y[i] : 0.f;
-        fz[r] = ok ? (float)c2.z[i] : 0.f;
+        const bool ok = wa0 + (int64_t)r * 64 + lane < a_end;
+        kl[r] = (LB && ok) ? lk[r] : -1;
+        fx[r] = ok ? (float)lx[r] : __builtin_nanf("");  // padded lane: dot = NaN fails every comparison (thresholds
+                                                          // are <= 0 for separations >= 90 degrees, so 0 would pass)
+        fy[r] = ok ? (float)ly[r] : 0.f;
+        fz[r] = ok ? (float)lz[r] : 0.f;
+    }
+    constexpr int RP = (R + 1) / 2;
+    v2f px[RP], py[RP], pz[RP];  // the same, packed in pairs for v_pk_*_f32 (R = 1: the upper half idles on NaN)
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+        const int r1 = 2 * q + 1 < R ? 2 * q + 1 : 2 * q;
+        px[q] = v2f{fx[2 * q], 2 * q + 1 < R ? fx[r1] : __builtin_nanf("")};
+        py[q] = v2f{fy[2 * q], fy[r1]};
+        pz[q] = v2f{fz[2 * q], fz[r1]};
     }
     // z-range of this wave's lane objects (+/- the window half width), as conservative float32 bounds
     // for comparison with the float32 z of the staged objects (monotone rounding keeps them conservative)
-    float wz_lo, wz_hi;
-    {
-        int64_t wa1 = wa0 + 64 * R;
-        if (wa1 > a_end) wa1 = a_end;
-        if (wa0 < wa1) {
-            const double lo = c2.key[wa0] - rwin, hi = c2.key[wa1 - 1] + rwin;
-            wz_lo = (float)lo;
-            if ((double)wz_lo > lo) wz_lo = nextafterf(wz_lo, -4.0f);
-            wz_hi = (float)hi;
-            if ((double)wz_hi < hi) wz_hi = nextafterf(wz_hi, 4.0f);
-        } else {  // wave without objects: empty range
-            wz_lo = 4.0f;
-            wz_hi = -4.0f;
-        }
+    float wz_lo = 4.0f, wz_hi = -4.0f;  // wave without objects: empty range
+    if (wave_has) {
+        const double lo = key_lo - rwin, hi = key_hi + rwin;
+        wz_lo = (float)lo;
+        if ((double)wz_lo > lo) wz_lo = nextafterf(wz_lo, -4.0f);
+        wz_hi = (float)hi;
+        if ((double)wz_hi < hi) wz_hi = nextafterf(wz_hi, 4.0f);
     }
-    for (int e = tid; e < nkb * n_edges; e += MWG) thr[e] = t[(int64_t)kfix * n_edges + e];
-    for (int e = tid; e < nkb; e += MWG) dth[e] = dthr[3 * (kfix + e)];
-    for (int e = tid; e < NHIST * nslots; e += MWG) hist[e] = HistT(0);
-    __syncthreads();
-
-    const int64_t nb_total = b1 - b0;
-    const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
-    auto fetch = [&](int64_t i) {  // float32 record of streamed object i; slots past the window never pass
-        ObjF o{0.f, 0.f, 0.f, 2.0f};
-        if (i < b1) o = ObjF{(float)c1.x[i], (float)c1.y[i], (float)c1.z[i], dth[MERGED ? c1.k[i] : 0]};
-        return o;
-    };
-    constexpr int NPF = (MSTAGE + MWG - 1) / MWG;  // stage slots a thread fills
 #pragma unroll
     for (int f = 0; f < NPF; ++f)
-        if (f * MWG + tid < MSTAGE) stagef[f * MWG + tid] = fetch(b0 + f * MWG + tid);
+        if (f * MWG + tid < MSTAGE) stagef[f * MWG + tid] = finish(first[f]);
     __syncthreads();
 
     int qn = 0;  // entries in this wave's survivor queue (wave-uniform)
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
         const int64_t sb0 = b0 + (int64_t)st * MSTAGE;  // global index of stage slot 0
-        ObjF nxt[NPF];
+        Raw nxt[NPF];
         const bool have_next = st + 1 < nstages;
 #pragma unroll
         for (int f = 0; f < NPF; ++f)
-            if (have_next && f * MWG + tid < MSTAGE) nxt[f] = fetch(sb0 + MSTAGE + f * MWG + tid);
+            if (have_next) nxt[f] = fetch_raw(sb0 + MSTAGE + f * MWG + tid);
         const int64_t left = nb_total - (int64_t)st * MSTAGE;
         const int n = left < MSTAGE ? (int)left : MSTAGE;
         const ObjF *curf = stagef + cb * MSTAGE;
@@ -552,15 +587,24 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
                 const unsigned int code = candq[wave * 64 + lane];
                 const int64_t ia = wa0 + (code >> 8);         // (r * 64 + lane) of the owner
                 const int64_t ib = sb0 + (code & 0xffu);      // stage slot
-                const double dx = c2.x[ia] - c1.x[ib];
-                const double dy = c2.y[ia] - c1.y[ib];
-                const double dz = c2.z[ia] - c1.z[ib];
+                // issue all gathers before the first use: one memory latency per drain, not three
+                const double ax = c2.x[ia], ay = c2.y[ia], az = c2.z[ia];
+                const double bx = c1.x[ib], by = c1.y[ib], bz = c1.z[ib];
+                const int kb = MERGED ? c1.k[ib] : 0;
+                double wa = 1.0, wb = 1.0;
+                if (WEIGHTED) {
+                    if (c2.w) wa = c2.w[ia];
+                    if (c1.w) wb = c1.w[ib];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double dx = ax - bx;
+                const double dy = ay - by;
+                const double dz = az - bz;
                 const double xx = dx * dx;
                 const double yy = dy * dy;
                 const double zz = dz * dz;
                 const double sxy = xx + yy;
                 const double s = sxy + zz;
-                const int kb = MERGED ? c1.k[ib] : 0;
                 const double *tk = thr + kb * n_edges;
                 if (s > tk[0] && s <= tk[n_edges - 1]) {
                     if (NF1) {
@@ -570,7 +614,7 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
                         for (int e = 0; e < n_edges; ++e) cnt += (s > tk[e]) ? 1 : 0;
                         hslot = kb * nf + cnt - 1;  // t[cnt-1] < s <= t[cnt], cnt >= 1 because s > t[0]
                     }
-                    if (WEIGHTED) val = (c2.w ? c2.w[ia] : 1.0) * (c1.w ? c1.w[ib] : 1.0);
+                    if (WEIGHTED) val = wa * wb;
                 }
             }
             if (!WEIGHTED) {
@@ -619,27 +663,37 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
         if (i_lo > MSTAGE - 2) i_lo = MSTAGE - 2;  // keeps the first read inside the stage; the loop is then empty
         // two streamed objects per trip, next pair prefetched from LDS while this one is evaluated.
         // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
-        ObjF c0 = curf[i_lo], c1r = curf[i_lo + 1];
-        for (int i = i_lo; i < i_hi; i += 2) {
-            const int ip = i + 2 < MSTAGE ? i + 2 : MSTAGE - 2;
-            const ObjF n0 = curf[ip], n1 = curf[ip + 1];
+        // One trip = two streamed objects against the R lane objects, in packed float32 (v_pk_mul/fma_f32:
+        // two lane objects per instruction). The loop is unrolled over two trips with alternating register
+        // sets so that the LDS prefetch of the next pair needs no register moves.
+        auto trip = [&](int i, const ObjF &c0, const ObjF &c1r) {
+            v2f e0[RP], e1[RP];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                e0[q] = __builtin_elementwise_fma(pz[q], v2f{c0.z, c0.z}, __builtin_elementwise_fma(py[q], v2f{c0.y, c0.y}, px[q] * v2f{c0.x, c0.x}));
+                e1[q] = __builtin_elementwise_fma(pz[q], v2f{c1r.z, c1r.z}, __builtin_elementwise_fma(py[q], v2f{c1r.y, c1r.y}, px[q] * v2f{c1r.x, c1r.x}));
+            }
             float d0[R], d1[R];
-            float best0 = -2.f, best1 = -2.f;
-            bool p0 = false, p1 = false;
-            const int kb0 = __float_as_int(c0.pad) & BIN_MASK, kb1 = __float_as_int(c1r.pad) & BIN_MASK;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                d0[r] = __builtin_fmaf(fz[r], c0.z, __builtin_fmaf(fy[r], c0.y, fx[r] * c0.x));
-                d1[r] = __builtin_fmaf(fz[r], c1r.z, __builtin_fmaf(fy[r], c1r.y, fx[r] * c1r.x));
-                if (LB) {
+                d0[r] = (r & 1) ? e0[r >> 1].y : e0[r >> 1].x;
+                d1[r] = (r & 1) ? e1[r >> 1].y : e1[r >> 1].x;
+            }
+            bool p0 = false, p1 = false;
+            if (LB) {
+                const int kb0 = __float_as_int(c0.pad) & BIN_MASK, kb1 = __float_as_int(c1r.pad) & BIN_MASK;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
                     p0 |= (d0[r] >= c0.pad) & (kl[r] == kb0);
                     p1 |= (d1[r] >= c1r.pad) & (kl[r] == kb1);
-                } else {
+                }
+            } else {
+                float best0 = d0[0], best1 = d1[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) {
                     best0 = fmaxf(best0, d0[r]);
                     best1 = fmaxf(best1, d1[r]);
                 }
-            }
-            if (!LB) {
                 p0 = best0 >= c0.pad;
                 p1 = best1 >= c1r.pad;
             }
@@ -647,13 +701,22 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
                 if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
                 if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
             }
-            c0 = n0;
-            c1r = n1;
+        };
+        // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
+        ObjF a0r = curf[i_lo], a1r = curf[i_lo + 1];
+        for (int i = i_lo; i < i_hi; i += 4) {
+            const int ib = i + 2 < MSTAGE ? i + 2 : MSTAGE - 2;
+            const ObjF b0r = curf[ib], b1r = curf[ib + 1];
+            trip(i, a0r, a1r);
+            const int ia = i + 4 < MSTAGE ? i + 4 : MSTAGE - 2;
+            a0r = curf[ia];
+            a1r = curf[ia + 1];
+            if (i + 2 < i_hi) trip(i + 2, b0r, b1r);
         }
         drain();  // codes refer to this stage's slots
 #pragma unroll
         for (int f = 0; f < NPF; ++f)
-            if (have_next && f * MWG + tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + f * MWG + tid] = nxt[f];
+            if (have_next && f * MWG + tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + f * MWG + tid] = finish(nxt[f]);
         __syncthreads();
     }
 
