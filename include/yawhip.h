@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YAWHIP_ABI_VERSION 1
+#define YAWHIP_ABI_VERSION 2
 
 typedef enum yawhip_status {
     YAWHIP_OK = 0,
@@ -57,8 +57,10 @@ typedef struct yawhip_stats {
     int64_t n_workgroups;      /* workgroups of the dominant (count) kernel                              */
     int32_t n_launches;        /* kernel launches in this call                                           */
     int32_t kernel_used;       /* yawhip_kernel actually run                                             */
-    double kernel_ms;          /* HIP-event time of the count kernel(s) on the context's stream          */
+    double kernel_ms;          /* HIP-event time of all launches of the call (item builder, count kernel,
+                                  reduction) on the context's stream                                     */
     double total_ms;           /* host wall time of the whole call (job upload, kernels, result download)*/
+    double count_ms;           /* HIP-event time of the count kernel(s) alone (ABI >= 2)                 */
 } yawhip_stats;
 
 const char *yawhip_last_error(void);
@@ -71,7 +73,14 @@ int yawhip_device_count(int *n);
 int yawhip_ctx_create(int device_id, yawhip_ctx **out);
 int yawhip_ctx_destroy(yawhip_ctx *ctx);
 
-/* Tunables (all optional): "tile_r" objects per lane (1,2,4), "kernel" default yawhip_kernel. */
+/* Tunables (all optional):
+ *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)
+ *   "kernel"            default yawhip_kernel of yawhip_count_pairs(kernel = AUTO)
+ *   "strip_width_micro" spacing, in 1e-6 chord units, of the strip grid of catalogues uploaded afterwards
+ *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
+ *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
+ *   "binned_strips"     1: binned x binned counts also use the strip layout (default 0)
+ *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 
 /*

@@ -49,6 +49,7 @@ class _Stats(ctypes.Structure):
         ("kernel_used", ctypes.c_int32),
         ("kernel_ms", ctypes.c_double),
         ("total_ms", ctypes.c_double),
+        ("count_ms", ctypes.c_double),
     ]
 
 
@@ -62,6 +63,7 @@ class CountStats:
     kernel_used: int = 0
     kernel_ms: float = 0.0
     total_ms: float = 0.0
+    count_ms: float = 0.0
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -120,8 +120,41 @@ struct alignas(16) Item {  // one unit of work for a workgroup
 //                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
 //                  dropped; survivors are appended with one atomic per wave (order is irrelevant).
 // ------------------------------------------------------------------------------------------------
+constexpr int BUILD_WG = 1024;  // threads per workgroup of the item builders
+
+// Append the kept items of a builder workgroup to the item list and add its evaluated-pair total: ONE atomic
+// per workgroup on each of the two counters. (They are single hot addresses -- with an atomic per wave the
+// builders spent three quarters of their time queueing on them.) Order of the list is irrelevant.
+__device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned long long work, Item *__restrict__ items,
+                                             unsigned long long *__restrict__ counters) {
+    __shared__ unsigned int s_cnt[BUILD_WG / 64];
+    __shared__ unsigned long long s_work[BUILD_WG / 64], s_base;
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
+    if (lane == 0) {
+        s_cnt[wave] = (unsigned int)__popcll(mask);
+        s_work[wave] = work;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int total = 0;
+        unsigned long long wsum = 0;
+        for (int wv = 0; wv < BUILD_WG / 64; ++wv) {
+            const unsigned int c = s_cnt[wv];
+            s_cnt[wv] = total;  // exclusive prefix
+            total += c;
+            wsum += s_work[wv];
+        }
+        s_base = total ? atomicAdd(&counters[0], (unsigned long long)total) : 0ull;
+        if (wsum) atomicAdd(&counters[1], wsum);
+    }
+    __syncthreads();
+    if (keep) items[s_base + s_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = it;
+}
+
 template <bool SWEEP>
-__global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
+__global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
                                                      const int64_t *__restrict__ prefix, int n_slots, int n_bins,
                                                      int tile, const double *__restrict__ rwin, int64_t n_pot,
                                                      Item *__restrict__ items, unsigned long long *__restrict__ counters) {
@@ -163,73 +196,92 @@ __global__ __launch_bounds__(256) void k_build_items(CatView c1, CatView c2, con
         work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
     }
     if (SWEEP) {
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-        const int lane = threadIdx.x & 63;
-        unsigned long long base = 0;
-        if (lane == 0 && mask) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (keep) items[base + __popcll(mask & ((1ull << lane) - 1ull))] = it;
-    } else if (pot < n_pot) {
-        items[pot] = it;
-        if (pot == 0) counters[0] = (unsigned long long)n_pot;  // every potential item is kept
+        append_items(keep, it, work, items, counters);
+    } else {
+        if (pot < n_pot) items[pot] = it;  // every potential item is kept
+        append_items(false, it, work, items, counters);
+        if (pot == 0) counters[0] = (unsigned long long)n_pot;
     }
-    // evaluated pairs: wave reduction, one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
-    if ((threadIdx.x & 63) == 0 && work) atomicAdd(&counters[1], work);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Item builder of the strip path. A sub-slot = (run of c1, run of c2, output slot): the pair of
-// (patch, strip) runs of one job that are close enough to hold pairs. One thread per potential item
-// (sub-slot, lane tile of the c2 run); window search and compaction as in k_build_items<true>.
-// sub[4*i] = {run in c1, run in c2, output slot, unused}.
+// Item builder of the strip path. A job (p, q) is cut into potential items
+//   (lane tile of a (patch q, strip) run of c2)  x  (one of the 2*reach+1 neighbouring strips of patch p in c1),
+// enumerated arithmetically: no per-job tables travel from the host. One thread per potential item finds its
+// job (prefix over jobs), its tile (prefix of tiles over the runs of c2) and the strip of c1 on the common
+// grid; window search and compaction as in k_build_items<true>.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_build_items_sub(const double *__restrict__ key1, const int64_t *__restrict__ off1,
-                                                         const double *__restrict__ key2, const int64_t *__restrict__ off2,
-                                                         const int32_t *__restrict__ sub, const int64_t *__restrict__ prefix,
-                                                         int n_sub, int tile, double rwin, int64_t n_pot,
-                                                         Item *__restrict__ items, unsigned long long *__restrict__ counters) {
+struct StripView {
+    const double *key;       // sort-axis column of the strip layout
+    const int64_t *off;      // [V+1] run offsets
+    const int64_t *vbase;    // [P+1] first run of a patch
+    const int64_t *slo;      // [P]   grid index of a patch's first run
+    const int64_t *tiles;    // [V+1] prefix of lane tiles over the runs (for the tile size of this call)
+};
+
+__global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, StripView c2, const int32_t *__restrict__ jobs,
+                                                            const int32_t *__restrict__ job_runs,
+                                                            const int64_t *__restrict__ prefix, int n_jobs, int reach,
+                                                            int tile, double rwin, int64_t n_pot,
+                                                            Item *__restrict__ items, unsigned long long *__restrict__ counters) {
     const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     Item it{};
     unsigned long long work = 0;
     if (pot < n_pot) {
-        int lo = 0, hi = n_sub;  // sub-slot = largest s with prefix[s] <= pot
+        int lo = 0, hi = n_jobs;  // job = largest j with prefix[j] <= pot
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (prefix[mid] <= pot) lo = mid; else hi = mid;
         }
-        const int r1 = sub[4 * lo], r2 = sub[4 * lo + 1], oslot = sub[4 * lo + 2];
-        int64_t b0 = off1[r1], b1 = off1[r1 + 1];
-        const int64_t a_seg1 = off2[r2 + 1];
-        const int64_t a0 = off2[r2] + (pot - prefix[lo]) * (int64_t)tile;
-        const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
-        const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
-        int64_t l = b0, h = b1;  // first index with key >= wlo
-        while (l < h) {
+        const int job = lo, p = jobs[2 * job], q = jobs[2 * job + 1];
+        // potential items of a job, in this order: run of patch q, neighbour offset d, lane tile of the run.
+        // Consecutive workgroups then stream adjacent windows of one c1 run and the three visits of a lane
+        // tile stay close in time (both sides hit in L2).
+        const int nd = 2 * reach + 1;
+        // runs of patch q whose grid index is within reach of some strip of patch p (host: job_runs)
+        const int64_t r_lo = c2.vbase[q] + job_runs[2 * job], r_hi = r_lo + job_runs[2 * job + 1];
+        const int64_t t_lo = c2.tiles[r_lo];
+        const int64_t local = pot - prefix[job];
+        int64_t l = r_lo, h = r_hi;  // run = largest r in [r_lo, r_hi) with nd * tiles-before-r <= local (skips empty runs)
+        while (h - l > 1) {
             const int64_t m = (l + h) >> 1;
-            if (key1[m] < wlo) l = m + 1; else h = m;
+            if ((c2.tiles[m] - t_lo) * nd <= local) l = m; else h = m;
         }
-        const int64_t first = l;
-        h = b1;  // first index with key > whi
-        while (l < h) {
-            const int64_t m = (l + h) >> 1;
-            if (key1[m] <= whi) l = m + 1; else h = m;
+        const int64_t r2 = l;
+        const int64_t run_tiles = c2.tiles[r2 + 1] - c2.tiles[r2];
+        const int64_t in_run = local - (c2.tiles[r2] - t_lo) * nd;
+        const int d = (int)(in_run / run_tiles) - reach;
+        const int64_t target = c2.tiles[r2] + in_run % run_tiles;
+        const int64_t s1 = c2.slo[q] + (r2 - c2.vbase[q]) + d - c1.slo[p];
+        if (s1 >= 0 && s1 < c1.vbase[p + 1] - c1.vbase[p]) {
+            const int64_t r1 = c1.vbase[p] + s1;
+            int64_t b0 = c1.off[r1], b1 = c1.off[r1 + 1];
+            const int64_t a_seg1 = c2.off[r2 + 1];
+            const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
+            const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
+            if (b1 > b0) {
+                const double wlo = c2.key[a0] - rwin, whi = c2.key[a1 - 1] + rwin;
+                l = b0; h = b1;  // first index with key >= wlo
+                while (l < h) {
+                    const int64_t m = (l + h) >> 1;
+                    if (c1.key[m] < wlo) l = m + 1; else h = m;
+                }
+                const int64_t first = l;
+                h = b1;  // first index with key > whi
+                while (l < h) {
+                    const int64_t m = (l + h) >> 1;
+                    if (c1.key[m] <= whi) l = m + 1; else h = m;
+                }
+                b0 = first;
+                b1 = l;
+            }
+            keep = b1 > b0;
+            it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = job; it.pot = (int32_t)pot;
+            work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
         }
-        b0 = first;
-        b1 = l;
-        keep = b1 > b0;
-        it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = oslot; it.pot = (int32_t)pot;
-        work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
     }
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
-    const int lane = threadIdx.x & 63;
-    unsigned long long base = 0;
-    if (lane == 0 && mask) base = atomicAdd(&counters[0], (unsigned long long)__popcll(mask));
-    base = __shfl(base, 0, 64);
-    if (keep) items[base + __popcll(mask & ((1ull << lane) - 1ull))] = it;
-    for (int off = 32; off > 0; off >>= 1) work += __shfl_down(work, off, 64);
-    if ((threadIdx.x & 63) == 0 && work) atomicAdd(&counters[1], work);
+    append_items(keep, it, work, items, counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,7 +509,7 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
                                                      int64_t item_base, unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials,
-                                                     const unsigned long long *__restrict__ n_kept) {
+                                                     const unsigned long long *__restrict__ counters) {
     constexpr bool MERGED = MODE != 0;
     constexpr bool LB = MODE == 2;  // lanes carry bin ids
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
@@ -472,8 +524,9 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = n_edges - 1;
-    if ((unsigned long long)(item_base + blockIdx.x) >= *n_kept) return;  // grid = potential items; the builder kept fewer
-    const Item it = items[item_base + blockIdx.x];
+    const unsigned long long ticket = item_base + blockIdx.x;
+    if (ticket >= counters[0]) return;  // never taken when the host sized the grid from the builder's count
+    const Item it = items[ticket];
     const int kfix = MERGED ? 0 : it.slot % n_bins;  // the item's bin (ordinary items)
     const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
     const int nslots = nkb * nf;
@@ -774,25 +827,16 @@ struct DevBuf {  // grow-only device workspace
 struct yawhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
     int binned_strips = 0;   // 1: binned x binned counts use the strip layout too (k_count_merged MODE 2)
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
+    int n_cu = 256;
     DevBuf<int32_t> d_jobs;
     DevBuf<int64_t> d_prefix;
-    DevBuf<int64_t> d_prefix_out;   // strip path: first potential item of every output slot
-    DevBuf<int32_t> d_sub;          // strip path: sub-slot table, 4 ints per entry
-    // the sub-slot tables of the last strip-path call stay on the device; a repeated call (DD, DR, ... of
-    // one measurement share the job list) reuses them
-    struct {
-        bool valid = false;
-        uint64_t serial1 = 0, serial2 = 0, jobs_hash = 0;
-        int n_jobs = 0;
-        int64_t reach = 0, tile = 0, n_items = 0, n_sub = 0;
-    } sub_cache;
     DevBuf<double> d_t;
     DevBuf<float> d_dthr;
     DevBuf<double> d_rwin;
@@ -811,7 +855,6 @@ struct yawhip_catalog {
     int64_t *off = nullptr;
     std::vector<int64_t> h_off;
     int64_t device_bytes = 0;
-    uint64_t serial = 0;    // unique per upload (keys the sub-slot cache)
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
     int axis = 2;           // coordinate the segments are sorted by (0 = x, 1 = y, 2 = z)
     // strip layout (every catalogue): each patch cut into strips of a global grid along a second axis
@@ -824,6 +867,8 @@ struct yawhip_catalog {
     std::vector<int64_t> h_moff;      // same on the host
     std::vector<int64_t> h_vbase;     // [P+1] first run of every patch
     std::vector<int64_t> h_slo;       // [P]   global strip index of a patch's first run
+    std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
+    int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
     double strip_width = 0.0;         // grid spacing (chord units); 0 = one run per patch
     int strip_axis = 0;
 };
@@ -960,13 +1005,17 @@ int yawhip_ctx_create(int device_id, yawhip_ctx **out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evc0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evc1);
     if (e != hipSuccess) {
         delete ctx;
         return fail(YAWHIP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.sharedMemPerBlock > 0)
-        ctx->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        if (prop.sharedMemPerBlock > 0) ctx->lds_limit = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+        if (prop.multiProcessorCount > 0) ctx->n_cu = prop.multiProcessorCount;
+    }
     *out = ctx;
     return YAWHIP_OK;
 }
@@ -977,8 +1026,6 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_jobs.release();
     ctx->d_prefix.release();
-    ctx->d_prefix_out.release();
-    ctx->d_sub.release();
     ctx->d_t.release();
     ctx->d_dthr.release();
     ctx->d_rwin.release();
@@ -989,6 +1036,8 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_partials.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evc0) (void)hipEventDestroy(ctx->evc0);
+    if (ctx->evc1) (void)hipEventDestroy(ctx->evc1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return YAWHIP_OK;
@@ -1053,8 +1102,6 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     HIP_TRY(hipSetDevice(ctx->device));
     yawhip_catalog *c = new (std::nothrow) yawhip_catalog();
     if (!c) return fail(YAWHIP_ERR_OOM, "host allocation failed");
-    static std::atomic<uint64_t> next_serial{1};
-    c->serial = next_serial.fetch_add(1);
     c->ctx = ctx;
     c->n = n;
     c->n_patches = n_patches;
@@ -1171,6 +1218,23 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
             e = hipMemcpyAsync(c->mk, sk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(c->moff, voff.data(), (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        // small per-run / per-patch tables the item builder walks on the device
+        for (int ri = 0; ri < 3; ++ri) {
+            const int64_t tile = (int64_t)MWG << ri;
+            c->h_tiles[ri].assign((size_t)n_runs + 1, 0);
+            for (int64_t r = 0; r < n_runs; ++r)
+                c->h_tiles[ri][(size_t)r + 1] = c->h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(c->d_tiles[ri], c->h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
+                                   hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_slo), (size_t)n_patches * sizeof(int64_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             yawhip_catalog_free(c);
@@ -1183,7 +1247,7 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         c->strip_width = width;
         c->strip_axis = saxis;
         c->device_bytes += (int64_t)col * (w ? 4 : 3) + (n_bins_or_1 > 1 ? n * (int64_t)sizeof(int32_t) : 0) +
-                           (n_runs + 1) * (int64_t)sizeof(int64_t);
+                           (4 * (n_runs + 1) + 2 * (int64_t)n_patches + 1) * (int64_t)sizeof(int64_t);
     }
     *out = c;
     return YAWHIP_OK;
@@ -1203,6 +1267,10 @@ int yawhip_catalog_free(yawhip_catalog *c) {
     if (c->mw) (void)hipFree(c->mw);
     if (c->mk) (void)hipFree(c->mk);
     if (c->moff) (void)hipFree(c->moff);
+    if (c->d_vbase) (void)hipFree(c->d_vbase);
+    if (c->d_slo) (void)hipFree(c->d_slo);
+    for (int ri = 0; ri < 3; ++ri)
+        if (c->d_tiles[ri]) (void)hipFree(c->d_tiles[ri]);
     delete c;
     return YAWHIP_OK;
 }
@@ -1298,62 +1366,40 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
-    // merged path: a job (p, q) is split into sub-slots (run of p, run of q) of strips close enough to hold
-    // pairs; slot = sub-slot for the builder, the items carry the job as their output slot.
-    std::vector<int64_t> prefix, prefix_out;
-    std::vector<int32_t> sub;
+    // strip path: slot = job; its potential items = (lane tiles of patch q) x (2*reach+1 neighbouring strips),
+    // enumerated by the builder kernel from the catalogues' run tables.
+    std::vector<int64_t> prefix;
+    std::vector<int32_t> job_runs;  // strip path, per job: first run of patch q (relative) and number of runs to visit
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
-    bool tables_cached = false;
-    int64_t n_sub = 0;
+    int reach = 0;
+    const int tile_idx = R == 1 ? 0 : (R == 2 ? 1 : 2);
     if (merged) {
         const double width = c1->strip_width;
         // |dv| <= rwin_max  ->  grid indices differ by at most floor(rwin_max / width) + 1
-        const int64_t reach = width > 0.0 ? (int64_t)std::floor(rwin_max / width + 1e-6) + 1 : 0;
-        uint64_t h = 1469598103934665603ull;  // FNV-1a of the job list
-        for (int i = 0; i < 2 * n_jobs; ++i) h = (h ^ (uint64_t)(uint32_t)jobs[i]) * 1099511628211ull;
-        auto &sc = ctx->sub_cache;
-        if (sc.valid && sc.serial1 == c1->serial && sc.serial2 == c2->serial && sc.jobs_hash == h && sc.n_jobs == n_jobs &&
-            sc.reach == reach && sc.tile == tile) {
-            tables_cached = true;
-            n_items = sc.n_items;
-            n_sub = sc.n_sub;
-        } else {
-            sc.valid = false;
-            prefix_out.resize((size_t)n_jobs + 1);
-            for (int j = 0; j < n_jobs; ++j) {
-                const int p = jobs[2 * j], q = jobs[2 * j + 1];
-                prefix_out[(size_t)j] = n_items;
-                const int64_t base1 = c1->h_vbase[(size_t)p], cnt1 = c1->h_vbase[(size_t)p + 1] - base1, lo1 = c1->h_slo[(size_t)p];
-                const int64_t base2 = c2->h_vbase[(size_t)q], cnt2 = c2->h_vbase[(size_t)q + 1] - base2, lo2 = c2->h_slo[(size_t)q];
-                for (int64_t s2 = 0; s2 < cnt2; ++s2) {
-                    const int64_t r2 = base2 + s2, n2 = c2->h_moff[(size_t)r2 + 1] - c2->h_moff[(size_t)r2];
-                    if (n2 == 0) continue;
-                    const int64_t g2 = lo2 + s2;
-                    const int64_t s1_lo = std::max<int64_t>(g2 - reach - lo1, 0), s1_hi = std::min<int64_t>(g2 + reach - lo1, cnt1 - 1);
-                    for (int64_t s1 = s1_lo; s1 <= s1_hi; ++s1) {
-                        const int64_t r1 = base1 + s1;
-                        if (c1->h_moff[(size_t)r1 + 1] == c1->h_moff[(size_t)r1]) continue;
-                        sub.push_back((int32_t)r1);
-                        sub.push_back((int32_t)r2);
-                        sub.push_back((int32_t)j);
-                        sub.push_back(0);
-                        prefix.push_back(n_items);
-                        n_items += (n2 + tile - 1) / tile;
-                    }
-                }
+        reach = width > 0.0 ? (int)std::floor(rwin_max / width + 1e-6) + 1 : 0;
+        prefix.resize((size_t)n_jobs + 1);
+        job_runs.assign((size_t)2 * n_jobs, 0);
+        const std::vector<int64_t> &tiles = c2->h_tiles[tile_idx];
+        for (int j = 0; j < n_jobs; ++j) {
+            const int p = jobs[2 * j], q = jobs[2 * j + 1];
+            prefix[(size_t)j] = n_items;
+            // strips of q whose grid index lies within `reach` of the strips patch p occupies
+            const int64_t cnt1 = c1->h_vbase[(size_t)p + 1] - c1->h_vbase[(size_t)p], lo1 = c1->h_slo[(size_t)p];
+            const int64_t cnt2 = c2->h_vbase[(size_t)q + 1] - c2->h_vbase[(size_t)q], lo2 = c2->h_slo[(size_t)q];
+            const int64_t s_lo = std::max<int64_t>(lo1 - reach - lo2, 0), s_hi = std::min<int64_t>(lo1 + cnt1 - 1 + reach - lo2, cnt2 - 1);
+            if (cnt1 > 0 && s_hi >= s_lo) {
+                const int64_t r0 = c2->h_vbase[(size_t)q] + s_lo;
+                job_runs[(size_t)2 * j] = (int32_t)s_lo;
+                job_runs[(size_t)2 * j + 1] = (int32_t)(s_hi - s_lo + 1);
+                n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * (2 * reach + 1);
             }
-            prefix_out[(size_t)n_jobs] = n_items;
-            prefix.push_back(n_items);
-            n_sub = (int64_t)prefix.size() - 1;
-            sc.serial1 = c1->serial; sc.serial2 = c2->serial; sc.jobs_hash = h; sc.n_jobs = n_jobs;
-            sc.reach = reach; sc.tile = tile; sc.n_items = n_items; sc.n_sub = n_sub;
         }
+        prefix[(size_t)n_jobs] = n_items;
     } else {
-        ctx->sub_cache.valid = false;  // d_prefix is about to be overwritten
         prefix.resize((size_t)n_slots + 1);
     }
-    const int64_t n_pslots = merged ? n_sub : n_slots;
+    const int64_t n_pslots = merged ? (int64_t)n_jobs : n_slots;
     for (int j = 0; j < n_jobs; ++j) {
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
@@ -1375,7 +1421,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool run_weighted = weighted && want_sums;
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
-    HIP_TRY(ctx->d_jobs.reserve((size_t)2 * n_jobs));
+    HIP_TRY(ctx->d_jobs.reserve((size_t)4 * n_jobs));
     HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
     HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
@@ -1401,17 +1447,11 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
     HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    if (!tables_cached)
-        HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
-                               ctx->stream));
-    if (merged && !tables_cached) {
-        HIP_TRY(ctx->d_prefix_out.reserve((size_t)n_jobs + 1));
-        HIP_TRY(ctx->d_sub.reserve(std::max<size_t>(sub.size(), 4)));
-        HIP_TRY(hipMemcpyAsync(ctx->d_prefix_out.ptr, prefix_out.data(), sizeof(int64_t) * ((size_t)n_jobs + 1),
+    if (merged)
+        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_jobs, job_runs.data(), sizeof(int32_t) * 2 * n_jobs,
                                hipMemcpyHostToDevice, ctx->stream));
-        if (!sub.empty())
-            HIP_TRY(hipMemcpyAsync(ctx->d_sub.ptr, sub.data(), sizeof(int32_t) * sub.size(), hipMemcpyHostToDevice, ctx->stream));
-    }
+    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
+                           ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * 3 * n_bins, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
@@ -1425,27 +1465,32 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     unsigned long long ctr[2] = {0ull, 0ull};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_pot > 0) {
-        if (n_pot >= (1ll << 31)) return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
+        if (n_pot >= (1ll << 31))
+            return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
         HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
-        HIP_TRY(ctx->d_ctr.reserve(2));
+        HIP_TRY(ctx->d_ctr.reserve(4));
         HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
         std::vector<double> rwin((size_t)n_bins);
         for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
         if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
-        const unsigned bgrid = (unsigned)((n_pot + 255) / 256);
+        const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
         if (merged)
-            hipLaunchKernelGGL(k_build_items_sub, dim3(bgrid), dim3(256), 0, ctx->stream,
-                               key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->moff, key_of(c2->mx, c2->my, c2->mz, c2->axis),
-                               c2->moff, ctx->d_sub.ptr, ctx->d_prefix.ptr, (int)n_pslots, (int)tile, rwin_max, n_pot,
+            hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream,
+                               StripView{key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->moff, c1->d_vbase, c1->d_slo,
+                                         c1->d_tiles[tile_idx]},
+                               StripView{key_of(c2->mx, c2->my, c2->mz, c2->axis), c2->moff, c2->d_vbase, c2->d_slo,
+                                         c2->d_tiles[tile_idx]},
+                               ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_jobs, ctx->d_prefix.ptr, n_jobs, reach,
+                               (int)tile, rwin_max, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr);
         else if (sweep)
-            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
+            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
                                ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr);
         else
-            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(256), 0, ctx->stream, view_of(c1), view_of(c2),
+            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr);
         HIP_TRY(hipGetLastError());
@@ -1454,9 +1499,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         // number the builder kept (device counter): no host round trip between the two kernels.
         HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
         n_items = n_pot;
+        if (merged) {
+            // The strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
+            // dispatching workgroups that exit at once (measured, 10M x 10M), more than this round trip costs.
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            n_items = (int64_t)ctr[0];
+        }
         if (run_weighted && sweep)  // dropped items leave their slab untouched
             HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
+    HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
     if (n_items > 0 && lean) {
         const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
                                      : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
@@ -1513,7 +1565,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             const int64_t n_oslots = merged ? (int64_t)n_jobs : n_slots;  // slabs are reduced per output slot
             const int64_t n_red = n_oslots * slab;
             hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_red + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                               ctx->d_partials.ptr, merged ? ctx->d_prefix_out.ptr : ctx->d_prefix.ptr, (int)n_oslots,
+                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_oslots,
                                (int)slab, ctx->d_sums.ptr);
             HIP_TRY(hipGetLastError());
             ++launches;
@@ -1539,6 +1591,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             ++launches;
         }
     }
+    HIP_TRY(hipEventRecord(ctx->evc1, ctx->stream));
     if (!weighted && want_sums) {
         const int thr = 256;
         hipLaunchKernelGGL(k_counts_to_double, dim3((unsigned)((n_out + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
@@ -1552,10 +1605,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (want_sums)
         HIP_TRY(hipMemcpyAsync(fine_sums, ctx->d_sums.ptr, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (merged) ctx->sub_cache.valid = true;  // tables are on the device now
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        float cms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&cms, ctx->evc0, ctx->evc1));
+        stats->count_ms = cms;
         stats->candidate_pairs = cand;
         stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
         stats->algorithmic_bytes = abytes;
