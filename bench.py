@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--tile-r", type=int, default=0, help="objects per lane (0 = library default)")
     ap.add_argument("--debug-no-hits", action="store_true", help="diagnostics: time the pre-filter only (wrong counts)")
     ap.add_argument("--strip-micro", type=int, default=None, help="strip grid spacing in 1e-6 chord units (0 = no strips)")
+    ap.add_argument("--scales", type=int, default=1, choices=[1, 3],
+                    help="1: one scale 1-10 arcmin; 3: the log-spaced scales of BASELINE config #5 (0.5-15.8 arcmin)")
+    ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5) on both catalogues")
     return ap.parse_args()
 
 
@@ -72,10 +75,18 @@ def make_catalogs(args):
 
     centers = yaw.AngularCoordinates(fibonacci_centers(args.patches))
     ra, dec, rng = uniform_sky(101, int(args.n_ref))
-    ref = yaw.Catalog.from_arrays(ra, dec, redshifts=rng.uniform(0.1, 1.0, len(ra)), patch_centers=centers, degrees=False)
-    ra, dec, _ = uniform_sky(202, int(args.n_unk))
-    unk = yaw.Catalog.from_arrays(ra, dec, patch_centers=centers, degrees=False)
-    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
+    z = rng.uniform(0.1, 1.0, len(ra))
+    weighted, scales = getattr(args, "weights", False), getattr(args, "scales", 1)
+    w = rng.uniform(0.5, 1.5, len(ra)) if weighted else None
+    ref = yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=w, patch_centers=centers, degrees=False)
+    ra, dec, rng = uniform_sky(202, int(args.n_unk))
+    w = rng.uniform(0.5, 1.5, len(ra)) if weighted else None
+    unk = yaw.Catalog.from_arrays(ra, dec, weights=w, patch_centers=centers, degrees=False)
+    if scales == 3:
+        rmin, rmax = [0.5, 1.58, 5.0], [1.58, 5.0, 15.8]
+    else:
+        rmin, rmax = 1.0, 10.0
+    config = yaw.Configuration.create(rmin=rmin, rmax=rmax, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
     return config, ref, unk
 
 
@@ -106,10 +117,13 @@ def cpu_baseline(links, ref, unk, budget_s):
     n_sample = int(np.clip(np.searchsorted(np.cumsum(cost), rate * budget_s), 1, len(jobs)))
     sample = jobs[:n_sample]
     t0 = time.perf_counter()
-    exp_counts, _ = oracle.count_jobs(c1, c2, sample, t)
+    exp_counts, exp_sums = oracle.count_jobs(c1, c2, sample, t)
     secs = time.perf_counter() - t0
     got, _ = engine.count_fine(l1, l2, sample, t)
-    parity = bool(np.array_equal(got, exp_counts.astype(np.float64)))
+    if l1.w is None and l2.w is None:  # integer counts: bit-identical
+        parity = bool(np.array_equal(got, exp_counts.astype(np.float64)))
+    else:                              # weighted sums: 1e-10 relative (north_star)
+        parity = bool(np.allclose(got, exp_sums, rtol=1e-10, atol=0.0))
     pairs = float(cost[:n_sample].sum())
     return dict(
         value=pairs / secs, unit="pairs/s", cores=oracle.num_threads(), kind="port",
@@ -244,7 +258,9 @@ def main():
             dtype="f64", data="synthetic",
             config=dict(
                 workload=f"{int(args.n_ref)} ref x {int(args.n_unk)} unk uniform full sky, {args.zbins} z-bins, "
-                         f"{args.patches} patches, 1 scale 1-10 arcmin, DD count of crosscorrelate",
+                         f"{args.patches} patches, "
+                         + ("1 scale 1-10 arcmin" if args.scales == 1 else "3 log scales 0.5-15.8 arcmin")
+                         + (", weighted" if args.weights else "") + ", DD count of crosscorrelate",
                 n_ref=int(args.n_ref), n_unk=int(args.n_unk), z_bins=args.zbins, patches=args.patches,
                 linked_patch_pairs=int(len(links.get_patch_pairs(ref, unk))), kernel=kernel_name,
                 parallelism=f"patch-pair sharding x{world}",

@@ -177,3 +177,36 @@ def test_headline_size_paths_agree():
     assert f_un.sum() == 0
     ref.drop_layouts()
     unk.drop_layouts()
+
+
+def test_headline_size_weighted_paths_agree():
+    """The same with per-object weights (w ~ U(0.5, 1.5)): the weighted sums of the strip path against the
+    FP32-filter path on a sample of jobs (different summation orders: 1e-12 relative), run-to-run bit
+    reproducibility of the strip path, and weighted sum / count = <w1 w2> ~ 1."""
+    import types
+
+    import bench
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import _lib, engine
+    from yet_another_wizz_amd.measurements import angular_plans, threshold_table
+
+    args = types.SimpleNamespace(n_ref=10e6, n_unk=10e6, patches=64, zbins=30, weights=True)
+    config, ref, unk = bench.make_catalogs(args)
+    lref = ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    lunk = unk.build_trees(None)
+    links = yaw.PatchLinkage.from_catalogs(config, ref, unk)
+    jobs = links.get_patch_pairs(ref, unk)
+    t = threshold_table(angular_plans(config))
+    s_sweep, st = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
+    s_again, _ = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
+    assert np.array_equal(s_sweep, s_again)
+    sample = jobs[::40]
+    s_filter, _ = engine.count_fine(lref, lunk, sample, t, kernel="filter")
+    np.testing.assert_allclose(s_sweep[::40], s_filter, rtol=1e-12, atol=0)
+    ctx = engine.get_context()
+    counts, sums, _ = _lib.count_pairs(ctx, engine.device_catalog(lref, ctx), engine.device_catalog(lunk, ctx), sample, t,
+                                       kernel="sweep", want_counts=True, want_sums=True)
+    assert np.array_equal(sums, s_sweep[::40]) and counts.sum() > 2e6
+    assert abs(sums.sum() / counts.sum() - 1.0) < 0.01
+    ref.drop_layouts()
+    unk.drop_layouts()

@@ -484,8 +484,8 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 // evaluates the exact predicate -- full lanes, one memory latency per 64 survivors. Hits go to a
 // [B][E-1] histogram in LDS:
 //   unweighted: uint32 LDS atomics (exact, order independent);
-//   weighted:   one float64 histogram per wave, lane 0 adds the wave's hits in queue order
-//               (stream order, r, lane) => bit-reproducible sums.
+//   weighted:   one float64 histogram per wave, updated with wave-private LDS float64 atomics
+//               (no other wave writes it => bit-reproducible sums, see the drain).
 // One item covers all B bins, so the c2 tile is read once per job instead of once per (job, bin).
 // ------------------------------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -673,15 +673,13 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
             if (!WEIGHTED) {
                 if (hslot >= 0) atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
             } else {
-                unsigned long long m = __builtin_amdgcn_ballot_w64(hslot >= 0);
-                while (m) {  // lane 0 adds the hits in queue order: deterministic summation
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int hs = __builtin_amdgcn_readlane(hslot, l);
-                    const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(val), l);
-                    const int hi32 = __builtin_amdgcn_readlane((int)__double2hiint(val), l);
-                    if (lane == 0) reinterpret_cast<double *>(hist)[wave * nslots + hs] += __hiloint2double(hi32, lo32);
-                }
+                // One LDS float64 atomic for the whole wave (ds_add_f64). The histogram belongs to this wave
+                // alone and a wave's LDS instructions execute in program order, so the only freedom is the order
+                // in which the LDS unit serialises lanes of ONE instruction that hit the same slot -- a fixed
+                // property of the hardware, not a race: sums are bit-reproducible from run to run
+                // (tests/test_gpu_scale_properties.py checks that at 10M x 10M).
+                double *wh = reinterpret_cast<double *>(hist) + wave * nslots;
+                if (hslot >= 0) atomicAdd(&wh[hslot], val);
             }
             qn = 0;
         };
