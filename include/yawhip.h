@@ -137,6 +137,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                        const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
                        int64_t *fine_counts, double *fine_sums, yawhip_stats *stats);
 
+/*
+ * Evaluated pair distances per job, without counting anything: runs the item builder of yawhip_count_pairs for the
+ * same arguments and sums lane-tile x window sizes per job (for the brute-force kernels that is N1*N2 per bin).
+ * This is the cost the host balances when it shards the job list over GPUs (replaces the "largest jobs first"
+ * scheduling heuristic of measurements.py:262-273). work: int64[n_jobs].
+ */
+int yawhip_job_work(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                    const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                    int64_t *work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,30 @@ def test_strips_cull_but_do_not_change_counts(setup):
     assert evaluated["auto"] < evaluated[20000]
 
 
+def test_job_work_is_what_the_device_evaluates(setup):
+    """``yawhip_job_work`` (the cost the host balances over GPUs): per-job figures add up to the
+    evaluated pairs of the real call, equal N1*N2 per job for the brute-force kernel, and an LPT
+    partition over them is a partition."""
+    from yet_another_wizz_amd import engine, parallel
+
+    s = setup
+    work = engine.job_work(s["lref"], s["lunk"], s["jobs"], s["t"], kernel="sweep")
+    assert work.dtype == np.int64 and work.shape == (len(s["jobs"]),)
+    assert work.sum() == s["stats"].evaluated_pairs and work.min() >= 0
+    diag = s["jobs"][:, 0] == s["jobs"][:, 1]
+    assert work[diag].mean() > 5 * work[~diag].mean()  # neighbours only share a boundary
+    brute = engine.job_work(s["lref"], s["lunk"], s["jobs"], s["t"], kernel="exact")
+    n1 = s["lref"].segment_sizes()[s["jobs"][:, 0]].sum(axis=1)
+    n2 = s["lunk"].segment_sizes()[s["jobs"][:, 1]].sum(axis=1)
+    assert np.array_equal(brute, n1 * n2) and brute.sum() == s["stats"].candidate_pairs
+    parts = parallel.partition_jobs(work.astype(float), 8)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(len(work)))
+    loads = np.array([work[p].sum() for p in parts], dtype=float)
+    assert loads.max() / loads.mean() < 1.15
+    again = engine.job_work(s["lref"], s["lunk"], s["jobs"], s["t"], kernel="sweep")
+    assert np.array_equal(work, again)  # exact function of the inputs: every rank derives the same partition
+
+
 def test_role_swap_symmetry(setup):
     """count(ref_p, unk_q) == count(unk_q, ref_p): lanes <-> stream, binned <-> unbinned."""
     from yet_another_wizz_amd import engine

@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "yawhip_catalog_free",
     "yawhip_catalog_device_bytes",
     "yawhip_count_pairs",
+    "yawhip_job_work",
 )
 
 
@@ -107,6 +108,9 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_count_pairs.argtypes = [
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
         _i64p, _dp, ctypes.POINTER(_Stats),
+    ]
+    lib.yawhip_job_work.argtypes = [
+        _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _i64p,
     ]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
@@ -241,3 +245,17 @@ def count_pairs(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresh
     )
     stats = CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
     return counts, sums, stats
+
+
+def job_work(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresholds, *, kernel="auto") -> np.ndarray:
+    """Run ``yawhip_job_work``: evaluated pair distances per job (int64[n_jobs]), nothing is counted."""
+    jobs = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2)
+    t = np.ascontiguousarray(thresholds, dtype=np.float64)
+    work = np.zeros(len(jobs), dtype=np.int64)
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    _check(
+        load_library().yawhip_job_work(ctx._h, c1._h, c2._h, len(jobs), _ptr(jobs, _i32p), t.shape[0], t.shape[1],
+                                       _ptr(t, _dp), kid, _ptr(work, _i64p)),
+        "yawhip_job_work",
+    )
+    return work

@@ -783,6 +783,15 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
     }
 }
 
+// Evaluated pairs per job (na * nb of the job's kept items): the cost the host balances over GPUs.
+__global__ void k_item_work(const Item *__restrict__ items, const unsigned long long *__restrict__ counters,
+                            int slots_per_job, unsigned long long *__restrict__ job_work) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= counters[0]) return;
+    const Item it = items[i];
+    atomicAdd(&job_work[it.slot / slots_per_job], (unsigned long long)it.na * (unsigned long long)it.nb);
+}
+
 // Sum the per-item slabs of every (job,bin) slot in item order (deterministic).
 __global__ void k_reduce_partials(const double *__restrict__ partials, const int64_t *__restrict__ prefix,
                                   int n_slots, int nf, double *__restrict__ out) {
@@ -843,6 +852,8 @@ struct yawhip_ctx {
     DevBuf<unsigned long long> d_counts;
     DevBuf<double> d_sums;
     DevBuf<double> d_partials;
+    DevBuf<unsigned long long> d_jobwork;
+    int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
 
 struct yawhip_catalog {
@@ -1032,6 +1043,7 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_counts.release();
     ctx->d_sums.release();
     ctx->d_partials.release();
+    ctx->d_jobwork.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evc0) (void)hipEventDestroy(ctx->evc0);
@@ -1506,6 +1518,19 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (run_weighted && sweep)  // dropped items leave their slab untouched
             HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
+    if (ctx->job_work_out) {  // cost estimate only: evaluated pairs per job from the item list, no counting
+        HIP_TRY(ctx->d_jobwork.reserve((size_t)n_jobs));
+        HIP_TRY(hipMemsetAsync(ctx->d_jobwork.ptr, 0, sizeof(unsigned long long) * (size_t)n_jobs, ctx->stream));
+        if (n_pot > 0) {
+            hipLaunchKernelGGL(k_item_work, dim3((unsigned)((n_pot + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_items.ptr,
+                               ctx->d_ctr.ptr, merged ? 1 : n_bins, ctx->d_jobwork.ptr);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->job_work_out, ctx->d_jobwork.ptr, sizeof(int64_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return YAWHIP_OK;
+    }
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
     if (n_items > 0 && lean) {
         const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
@@ -1619,6 +1644,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
     return YAWHIP_OK;
+}
+
+int yawhip_job_work(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs,
+                    int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel, int64_t *work) {
+    if (!ctx || !work) return fail(YAWHIP_ERR_INVALID, "yawhip_job_work: NULL argument");
+    for (int j = 0; j < n_jobs; ++j) work[j] = 0;
+    ctx->job_work_out = work;
+    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, nullptr, nullptr, nullptr);
+    ctx->job_work_out = nullptr;
+    return rc;
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .parallel import local_device_index
 
-__all__ = ["get_context", "device_catalog", "count_fine", "release", "default_kernel"]
+__all__ = ["get_context", "device_catalog", "count_fine", "job_work", "release", "default_kernel"]
 
 _contexts: dict = {}
 default_kernel = "auto"
@@ -71,13 +71,23 @@ def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None,
 
     Unweighted catalogues are counted in int64 on the device and converted exactly
     (the reference's ``.astype(np.float64)``, trees.py:353)."""
-    ctx = get_context()
-    micro = forced_strip_micro if forced_strip_micro is not None else strip_micro_for(thresholds)
-    d1 = device_catalog(layout1, ctx, sort_axis, micro, exact=forced_strip_micro is not None)
-    if layout2 is layout1:
-        d2 = d1
-    else:
-        d2 = device_catalog(layout2, ctx, sort_axis, d1.strip_micro, exact=True)  # both sides on the same grid
+    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis)
     counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)
     fine = sums if sums is not None else counts.astype(np.float64)
     return fine, stats
+
+
+def _device_pair(layout1, layout2, thresholds, sort_axis):
+    ctx = get_context()
+    micro = forced_strip_micro if forced_strip_micro is not None else strip_micro_for(thresholds)
+    d1 = device_catalog(layout1, ctx, sort_axis, micro, exact=forced_strip_micro is not None)
+    d2 = d1 if layout2 is layout1 else device_catalog(layout2, ctx, sort_axis, d1.strip_micro, exact=True)
+    return ctx, d1, d2
+
+
+def job_work(layout1, layout2, jobs, thresholds, *, kernel: str | None = None, sort_axis: int = 2) -> np.ndarray:
+    """Pair distances the device will evaluate for every job (int64[n_jobs]; ``yawhip_job_work``): the
+    cost ``PatchLinkage.count_pairs`` balances when it shards the job list over GPUs. It is an exact
+    function of the inputs, so every rank derives the same partition."""
+    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis)
+    return _lib.job_work(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)

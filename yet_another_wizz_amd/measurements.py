@@ -98,8 +98,13 @@ def threshold_table(plans) -> np.ndarray:
     return table
 
 
+JOB_FIXED_COST = 2.0e5  # evaluated-pair equivalent of touching a job at all (launch share, empty windows)
+
+
 def job_costs(layout1, layout2, jobs, thresholds, tile: int = 1024) -> np.ndarray:
-    """Estimated device work per job, used to balance jobs over GPUs.
+    """Host-side estimate of the device work per job (no GPU involved). ``PatchLinkage.count_pairs``
+    balances the exact figure from the device instead (``engine.job_work``); this one serves the CPU
+    tests of the sharding logic and as a documented model of the culling.
 
     Brute force would cost N1*N2; the z-window culling of the device path only evaluates the part
     of patch 1 within (tile extent + 2 r_max) in z of each lane tile of patch 2, so a job costs about
@@ -138,6 +143,7 @@ class PatchLinkage:
         self._plans = None
         self._thresholds = None
         self._job_tables: dict = {}
+        self._partitions: dict = {}
 
     def _angular_setup(self):
         if self._plans is None:
@@ -227,7 +233,13 @@ class PatchLinkage:
         rank, size = parallel.world()
         mine = np.arange(len(jobs))
         if size > 1:
-            mine = parallel.partition_jobs(job_costs(layout1, layout2, jobs, thresholds), size)[rank]
+            # balance what the device will really evaluate (lane tile x window sizes, from the item builder);
+            # the partition is a plan: derived once per (catalogue pair, group size) and reused
+            key = (id(layout1), id(layout2), len(layout1.x), len(layout2.x), len(jobs), auto, size)
+            if key not in self._partitions:
+                work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
+                self._partitions[key] = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
+            mine = self._partitions[key][rank]
         fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis)
         self.last_stats = stats
 
