@@ -243,15 +243,17 @@ class PatchLinkage:
         fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis)
         self.last_stats = stats
 
-        # fine[b, e, j]: fine-bin counts of every job. With several ranks each one fills its own slots of a
-        # zero-initialised dense [B, E-1, P, P] tensor and one sum all-reduce combines them (every slot is
-        # non-zero on exactly one rank, so the sum is exact and order independent).
+        # fine[b, e, j]: fine-bin counts of every job. With several ranks each one fills its own rows of a
+        # zero-initialised tensor and one sum all-reduce combines them (every slot is non-zero on exactly one
+        # rank, so the sum is exact and order independent).
         id1, id2 = jobs[:, 0], jobs[:, 1]
         if size > 1:
-            dense = np.zeros((num_bins, num_fine, num_patches, num_patches), dtype=np.float64)
+            # only linked patch pairs carry counts: the tensor travels in its compact [jobs, B, E-1] form
+            # (every rank holds the same job table), 9x smaller than the dense [B, E-1, P, P] at 64 patches
+            compact = np.zeros((len(jobs), num_bins, num_fine), dtype=np.float64)
             if len(mine):
-                dense[:, :, jobs[mine, 0], jobs[mine, 1]] = np.moveaxis(fine, 0, -1)
-            fine_bej = parallel.allreduce_sum(dense)[:, :, id1, id2]
+                compact[mine] = fine
+            fine_bej = np.moveaxis(parallel.allreduce_sum(compact), 0, -1)
         else:
             fine_bej = np.moveaxis(fine, 0, -1)
 
