@@ -13,9 +13,13 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-SRC = os.path.join(PKG_DIR, "csrc", "yawhip.hip")
+CSRC = os.path.join(PKG_DIR, "csrc")
+SOURCES = [os.path.join(CSRC, "yawhip.hip"), os.path.join(CSRC, "yawhip_sort.hip")]
+HEADERS = [os.path.join(ROOT, "include", "yawhip.h"), os.path.join(CSRC, "yawhip_sort.h")]
+SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG_DIR, "libyawhip.so")
+OBJ_DIR = os.path.join(PKG_DIR, "build")
 
 # -ffp-contract=off: the inclusion predicate must round every product and sum separately (no FMA)
 HIPCC_FLAGS = [
@@ -23,7 +27,6 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-std=c++17",
     "-fPIC",
-    "-shared",
     "-ffp-contract=off",
     "-fno-fast-math",
     "-Wall",
@@ -41,14 +44,32 @@ def hipcc_path() -> str:
 def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
-    newest = max(os.path.getmtime(p) for p in (SRC, os.path.join(INCLUDE, "yawhip.h")))
+    newest = max(os.path.getmtime(p) for p in (*SOURCES, *HEADERS))
     return os.path.getmtime(LIB) < newest
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    if not force and not is_stale():
+    """Compile every source to an object (objects of unchanged sources are reused unless ``force`` or
+    ``extra_flags`` are given: the rocPRIM sorts take 30 s, the kernels are what one iterates on) and link."""
+    if not force and not extra_flags and not is_stale():
         return LIB
-    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, f"-I{INCLUDE}", "-o", LIB, SRC]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = hipcc_path()
+    newest_header = max(os.path.getmtime(p) for p in HEADERS)
+    objects = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objects.append(obj)
+        is_kernels = src == SOURCES[0]
+        flags = list(extra_flags) if is_kernels else []  # experiment flags only concern the kernels
+        fresh = os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header)
+        if fresh and not flags and not (force and is_kernels) and not (force == "all"):
+            continue
+        cmd = [hipcc, *HIPCC_FLAGS, *flags, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objects]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -56,4 +77,4 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="all" if "--all" in sys.argv else "--force" in sys.argv, verbose=True))

@@ -33,6 +33,7 @@
 #include <numeric>
 #include <thread>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -42,6 +43,7 @@
 #include <vector>
 
 #include "yawhip.h"
+#include "yawhip_sort.h"
 
 namespace {
 
@@ -853,6 +855,7 @@ struct yawhip_ctx {
     DevBuf<double> d_sums;
     DevBuf<double> d_partials;
     DevBuf<unsigned long long> d_jobwork;
+    yawsort::Workspace sort_ws;  // upload-side sorts
     int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
 
@@ -930,47 +933,69 @@ hipError_t launch_count_any(bool priv, bool filter, int r, yawhip_ctx *ctx, cons
                   : launch_count_r<W, false, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
 }
 
-// Sort every (patch, bin) segment by the key column (ties by original index, so the order is deterministic).
-// Returns the permutation; segments are independent, a few host threads share them.
-std::vector<int64_t> sort_segments_by_key(int64_t n, const double *z, const int64_t *offsets, int64_t nseg) {
-    std::vector<int64_t> perm((size_t)n);
-    std::iota(perm.begin(), perm.end(), (int64_t)0);
-    std::atomic<int64_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const int64_t sgm = next.fetch_add(1);
-            if (sgm >= nseg) break;
-            std::sort(perm.begin() + offsets[sgm], perm.begin() + offsets[sgm + 1],
-                      [z](int64_t a, int64_t b) { return z[a] < z[b] || (z[a] == z[b] && a < b); });
-        }
-    };
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_threads = n < (1 << 16) ? 1u : std::min(std::max(hw, 1u), 16u);
-    std::vector<std::thread> pool;
-    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
-    worker();
-    for (auto &th : pool) th.join();
-    return perm;
+// ---- upload-side kernels: ordering of a catalogue on the device (the sorts themselves: yawhip_sort.hip) ----
+__global__ void k_gather_columns(int64_t n, const uint32_t *__restrict__ perm, const double *__restrict__ sx,
+                                 const double *__restrict__ sy, const double *__restrict__ sz, const double *__restrict__ sw,
+                                 double *__restrict__ dx, double *__restrict__ dy, double *__restrict__ dz, double *__restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = perm[i];
+    dx[i] = sx[src];
+    dy[i] = sy[src];
+    dz[i] = sz[src];
+    if (sw) dw[i] = sw[src];
 }
 
-// Same for an index vector that is already grouped into runs (strip layout).
-void sort_runs_by_key(std::vector<int64_t> &idx, const double *z, const int64_t *offsets, int64_t nseg) {
-    std::atomic<int64_t> next{0};
-    auto worker = [&]() {
-        for (;;) {
-            const int64_t lo = next.fetch_add(64);
-            if (lo >= nseg) break;
-            for (int64_t sgm = lo; sgm < std::min(lo + 64, nseg); ++sgm)
-                std::sort(idx.begin() + offsets[sgm], idx.begin() + offsets[sgm + 1],
-                          [z](int64_t a, int64_t b) { return z[a] < z[b] || (z[a] == z[b] && a < b); });
-        }
-    };
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_threads = idx.size() < (1u << 16) ? 1u : std::min(std::max(hw, 1u), 16u);
-    std::vector<std::thread> pool;
-    for (unsigned i = 1; i < n_threads; ++i) pool.emplace_back(worker);
-    worker();
-    for (auto &th : pool) th.join();
+// largest s in [0, n_seg) with off[s] <= i (off[0] = 0 <= i < off[n_seg])
+__device__ __forceinline__ int segment_of(const int64_t *__restrict__ off, int n_seg, int64_t i) {
+    int lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// bin id of every object of the strip layout = its (patch, bin) segment in the input order, modulo B
+__global__ void k_gather_bins(int64_t n, const uint32_t *__restrict__ perm, const int64_t *__restrict__ off, int64_t n_seg,
+                              int n_bins, int32_t *__restrict__ bins) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bins[i] = segment_of(off, (int)n_seg, (int64_t)perm[i]) % n_bins;
+}
+
+// grid index floor((v + 1) / width) of every object (0 without strips) and the occupied range per patch
+__global__ void k_strip_index(int64_t n, const double *__restrict__ v, double width, const int64_t *__restrict__ poff,
+                              int n_patches, int32_t *__restrict__ gidx, int32_t *__restrict__ lohi) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t g = width > 0.0 ? (int32_t)floor((v[i] + 1.0) / width) : 0;
+    gidx[i] = g;
+    const int p = segment_of(poff, n_patches, i);
+    atomicMin(&lohi[2 * p], g);
+    atomicMax(&lohi[2 * p + 1], g);
+}
+
+// run id of the object that is i-th in `order` (objects of a patch are contiguous in the input)
+__global__ void k_run_of(int64_t n, const uint32_t *__restrict__ order, const int32_t *__restrict__ gidx,
+                         const int64_t *__restrict__ poff, int n_patches, const int64_t *__restrict__ vbase,
+                         const int64_t *__restrict__ slo, uint32_t *__restrict__ run) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = order[i];
+    const int p = segment_of(poff, n_patches, (int64_t)src);
+    run[i] = (uint32_t)(vbase[p] + (int64_t)gidx[src] - slo[p]);
+}
+
+// moff[r] = first position of the (sorted) run column that holds a run >= r; moff[n_runs] = n
+__global__ void k_run_offsets(const uint32_t *__restrict__ run_sorted, int64_t n, int64_t n_runs, int64_t *__restrict__ moff) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_runs) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)run_sorted[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    moff[r] = lo;
 }
 
 inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
@@ -1044,6 +1069,7 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_sums.release();
     ctx->d_partials.release();
     ctx->d_jobwork.release();
+    ctx->sort_ws.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evc0) (void)hipEventDestroy(ctx->evc0);
@@ -1106,6 +1132,7 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     if (n < 0 || n_patches <= 0 || n_bins_or_1 <= 0 || !offsets || (n > 0 && (!x || !y || !z)))
         return fail(YAWHIP_ERR_INVALID, "yawhip_catalog_upload: bad sizes or NULL columns");
     const int64_t nseg = (int64_t)n_patches * n_bins_or_1;
+    if (n >= (1ll << 32)) return fail(YAWHIP_ERR_INVALID, "at most 2^32 - 1 objects per catalogue");
     if (offsets[0] != 0 || offsets[nseg] != n) return fail(YAWHIP_ERR_INVALID, "offsets must start at 0 and end at n");
     for (int64_t i = 0; i < nseg; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(YAWHIP_ERR_INVALID, "offsets must be non-decreasing");
@@ -1122,113 +1149,118 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         const double n2 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
         if (!(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL)) c->unit_norm = false;
     }
-    // library-private order inside a segment: ascending along the sort axis (enables the SWEEP windows)
-    std::vector<double> sx, sy, sz, sw;
-    try {
-        const std::vector<int64_t> perm = sort_segments_by_key(n, key_of(x, y, z, sort_axis), offsets, nseg);
-        auto gather = [&](const double *src, std::vector<double> &dst) {
-            dst.resize((size_t)n);
-            for (int64_t i = 0; i < n; ++i) dst[(size_t)i] = src[perm[(size_t)i]];
-        };
-        gather(x, sx);
-        gather(y, sy);
-        gather(z, sz);
-        if (w) gather(w, sw);
-    } catch (const std::exception &ex) {
-        delete c;
-        return fail(YAWHIP_ERR_OOM, "host-side segment sort failed: %s", ex.what());
-    }
+    // Library-private order: the columns go to the device as they are and are ordered there (rocPRIM radix sorts,
+    // yawhip_sort.hip): ascending along the sort axis inside every (patch, bin) segment, and the strip layout.
     const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    double *rx = nullptr, *ry = nullptr, *rz = nullptr, *rw = nullptr;  // raw columns (temporary)
+    uint32_t *perm = nullptr, *perm2 = nullptr, *run = nullptr, *run_sorted = nullptr;
+    int32_t *gidx = nullptr, *lohi = nullptr;
+    int64_t *poff = nullptr;
+    auto free_tmp = [&]() {
+        for (void *q : {(void *)rx, (void *)ry, (void *)rz, (void *)rw, (void *)perm, (void *)perm2, (void *)run,
+                        (void *)run_sorted, (void *)gidx, (void *)lohi, (void *)poff})
+            if (q) (void)hipFree(q);
+    };
+    auto bail = [&](hipError_t err, const char *what) {
+        free_tmp();
+        yawhip_catalog_free(c);
+        return fail(err == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (%s) failed: %s", what,
+                    hipGetErrorString(err));
+    };
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->x), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->y), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->z), col);
     if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->w), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->off), (size_t)(nseg + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rx), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ry), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rz), col);
+    if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&rw), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm), (size_t)std::max<int64_t>(n, 1) * sizeof(uint32_t));
     if (e == hipSuccess && n > 0) {
-        e = hipMemcpyAsync(c->x, sx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->y, sy.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->z, sz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && w)
-            e = hipMemcpyAsync(c->w, sw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(rx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ry, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(rz, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && w) e = hipMemcpyAsync(rw, w, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->off, offsets, (size_t)(nseg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        yawhip_catalog_free(c);
-        return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload failed: %s",
-                    hipGetErrorString(e));
+    if (e != hipSuccess) return bail(e, "columns");
+    const unsigned ngrid = (unsigned)((std::max<int64_t>(n, 1) + 255) / 256);
+    if (n > 0) {
+        e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(rx, ry, rz, sort_axis), c->off, nseg, perm);
+        if (e != hipSuccess) return bail(e, "segment sort");
+        hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, rx, ry, rz, rw, c->x, c->y, c->z, c->w);
+        if ((e = hipGetLastError()) != hipSuccess) return bail(e, "gather");
     }
     c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
     if (c->unit_norm && n > 0) {
-        // second, strip layout for the cross-correlation fast path: runs of (patch, strip), all bins together,
-        // sorted along the sort axis inside a run. Strips are cells of a global grid along strip_axis, so that
-        // runs of different catalogues can be paired by their grid index alone.
+        // Strip layout for the cross-correlation fast path: runs of (patch, strip), all bins together, sorted along
+        // the sort axis inside a run. Strips are cells of a global grid along strip_axis, so that runs of different
+        // catalogues can be paired by their grid index alone.
         const double width = ctx->strip_width;
         const int saxis = (sort_axis + 2) % 3;  // z -> y, y -> x, x -> z
-        const double *v = key_of(x, y, z, saxis);
-        auto strip_of = [width, v](int64_t i) -> int64_t { return width > 0.0 ? (int64_t)std::floor((v[i] + 1.0) / width) : 0; };
-        std::vector<int64_t> vbase((size_t)n_patches + 1, 0), slo((size_t)n_patches, 0), voff;
-        std::vector<int32_t> kk, sk;
-        try {
-            for (int p = 0; p < n_patches; ++p) {
-                const int64_t i0 = offsets[(int64_t)p * n_bins_or_1], i1 = offsets[(int64_t)(p + 1) * n_bins_or_1];
-                int64_t lo = 0, hi = -1;
-                for (int64_t i = i0; i < i1; ++i) {
-                    const int64_t g = strip_of(i);
-                    if (hi < lo) lo = hi = g;
-                    lo = std::min(lo, g);
-                    hi = std::max(hi, g);
-                }
-                slo[(size_t)p] = lo;
-                vbase[(size_t)p + 1] = vbase[(size_t)p] + (hi - lo + 1);  // an empty patch has no runs
-            }
-            const int64_t n_runs = vbase[(size_t)n_patches];
-            voff.assign((size_t)n_runs + 1, 0);
-            std::vector<int64_t> run((size_t)n);
-            for (int p = 0; p < n_patches; ++p)
-                for (int64_t i = offsets[(int64_t)p * n_bins_or_1]; i < offsets[(int64_t)(p + 1) * n_bins_or_1]; ++i) {
-                    run[(size_t)i] = vbase[(size_t)p] + strip_of(i) - slo[(size_t)p];
-                    ++voff[(size_t)run[(size_t)i] + 1];
-                }
-            for (int64_t r = 0; r < n_runs; ++r) voff[(size_t)r + 1] += voff[(size_t)r];
-            // bucket by run (stable), then sort every run along the sort axis
-            std::vector<int64_t> fill(voff.begin(), voff.end() - 1), bucket((size_t)n);
-            for (int64_t i = 0; i < n; ++i) bucket[(size_t)fill[(size_t)run[(size_t)i]]++] = i;
-            if (n_bins_or_1 > 1) {
-                kk.resize((size_t)n);
-                sk.resize((size_t)n);
-                for (int64_t sgm = 0; sgm < nseg; ++sgm)
-                    for (int64_t i = offsets[sgm]; i < offsets[sgm + 1]; ++i) kk[(size_t)i] = (int32_t)(sgm % n_bins_or_1);
-            }
-            sort_runs_by_key(bucket, key_of(x, y, z, sort_axis), voff.data(), n_runs);
-            for (int64_t i = 0; i < n; ++i) {
-                const int64_t src = bucket[(size_t)i];
-                sx[(size_t)i] = x[src]; sy[(size_t)i] = y[src]; sz[(size_t)i] = z[src];
-                if (w) sw[(size_t)i] = w[src];
-                if (n_bins_or_1 > 1) sk[(size_t)i] = kk[(size_t)src];
-            }
-        } catch (const std::exception &ex) {
-            yawhip_catalog_free(c);
-            return fail(YAWHIP_ERR_OOM, "host-side strip layout failed: %s", ex.what());
+        std::vector<int64_t> h_poff((size_t)n_patches + 1);
+        for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
+        std::vector<int32_t> h_lohi((size_t)2 * n_patches);
+        for (int p = 0; p < n_patches; ++p) { h_lohi[(size_t)2 * p] = INT32_MAX; h_lohi[(size_t)2 * p + 1] = INT32_MIN; }
+        e = hipMalloc(reinterpret_cast<void **>(&poff), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&lohi), (size_t)2 * n_patches * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&gidx), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm2), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run_sorted), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(poff, h_poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(lohi, h_lohi.data(), (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return bail(e, "strip tables");
+        // grid index of every object, first / last occupied strip of every patch
+        hipLaunchKernelGGL(k_strip_index, dim3(ngrid), dim3(256), 0, ctx->stream, n, key_of(rx, ry, rz, saxis), width, poff,
+                           n_patches, gidx, lohi);
+        e = hipMemcpyAsync(h_lohi.data(), lohi, (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return bail(e, "strip index");
+        std::vector<int64_t> vbase((size_t)n_patches + 1, 0), slo((size_t)n_patches, 0);
+        for (int p = 0; p < n_patches; ++p) {
+            const bool any = h_poff[(size_t)p + 1] > h_poff[(size_t)p];
+            slo[(size_t)p] = any ? h_lohi[(size_t)2 * p] : 0;
+            vbase[(size_t)p + 1] = vbase[(size_t)p] + (any ? (int64_t)h_lohi[(size_t)2 * p + 1] - h_lohi[(size_t)2 * p] + 1 : 0);
         }
         const int64_t n_runs = vbase[(size_t)n_patches];
+        if (n_runs >= (1ll << 31)) return bail(hipErrorInvalidValue, "too many strip runs");
+        int run_bits = 1;
+        while ((1ll << run_bits) < n_runs) ++run_bits;
+        e = hipMalloc(reinterpret_cast<void **>(&c->d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_slo), (size_t)n_patches * sizeof(int64_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        // order along the sort axis inside every patch, then group by run (unique keys (run, rank): no reliance on
+        // the stability of the sort)
+        if (e == hipSuccess) e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(rx, ry, rz, sort_axis), poff, n_patches, perm);
+        if (e != hipSuccess) return bail(e, "patch sort");
+        hipLaunchKernelGGL(k_run_of, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, gidx, poff, n_patches, c->d_vbase, c->d_slo, run);
+        e = yawsort::sort_runs(ctx->sort_ws, ctx->stream, n, run, perm, run_bits, perm2, run_sorted);
+        if (e != hipSuccess) return bail(e, "run sort");
         e = hipMalloc(reinterpret_cast<void **>(&c->mx), col);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->my), col);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mz), col);
         if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->mw), col);
         if (e == hipSuccess && n_bins_or_1 > 1) e = hipMalloc(reinterpret_cast<void **>(&c->mk), (size_t)n * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->moff), (size_t)(n_runs + 1) * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMemcpyAsync(c->mx, sx.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->my, sy.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(c->mz, sz.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && w)
-            e = hipMemcpyAsync(c->mw, sw.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess && n_bins_or_1 > 1)
-            e = hipMemcpyAsync(c->mk, sk.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(c->moff, voff.data(), (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        // small per-run / per-patch tables the item builder walks on the device
+        if (e != hipSuccess) return bail(e, "strip layout");
+        hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, rx, ry, rz, rw, c->mx, c->my, c->mz, c->mw);
+        if (n_bins_or_1 > 1)
+            hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, n_bins_or_1, c->mk);
+        hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
+                           c->moff);
+        std::vector<int64_t> voff((size_t)n_runs + 1);
+        e = hipMemcpyAsync(voff.data(), c->moff, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return bail(e, "run offsets");
+        // small per-run tables the item builder walks on the device
         for (int ri = 0; ri < 3; ++ri) {
             const int64_t tile = (int64_t)MWG << ri;
             c->h_tiles[ri].assign((size_t)n_runs + 1, 0);
@@ -1239,18 +1271,7 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
                 e = hipMemcpyAsync(c->d_tiles[ri], c->h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
                                    hipMemcpyHostToDevice, ctx->stream);
         }
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_slo), (size_t)n_patches * sizeof(int64_t));
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(c->d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(c->d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
-            yawhip_catalog_free(c);
-            return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (strip layout) failed: %s",
-                        hipGetErrorString(e));
-        }
+        if (e != hipSuccess) return bail(e, "tile tables");
         c->h_moff = std::move(voff);
         c->h_vbase = std::move(vbase);
         c->h_slo = std::move(slo);
@@ -1259,6 +1280,9 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         c->device_bytes += (int64_t)col * (w ? 4 : 3) + (n_bins_or_1 > 1 ? n * (int64_t)sizeof(int32_t) : 0) +
                            (4 * (n_runs + 1) + 2 * (int64_t)n_patches + 1) * (int64_t)sizeof(int64_t);
     }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(e, "finish");
+    free_tmp();
     *out = c;
     return YAWHIP_OK;
 }
