@@ -138,6 +138,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                        int64_t *fine_counts, double *fine_sums, yawhip_stats *stats);
 
 /*
+ * Nearest patch centre of n objects in Euclidean xyz (replaces scipy.cluster.vq.vq in assign_patch_centers,
+ * catalog/catalog.py:229-249, same arithmetic: identical ids including ties, first minimum wins).
+ *   x,y,z        float64[n] unit vectors (host)
+ *   centers_xyz  float64[n_centers][3] (host, row-major)
+ *   patch_out    int32[n] (host)
+ */
+int yawhip_assign_patches(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
+                          int32_t n_centers, const double *centers_xyz, int32_t *patch_out);
+
+/*
  * Evaluated pair distances per job, without counting anything: runs the item builder of yawhip_count_pairs for the
  * same arguments and sums lane-tile x window sizes per job (for the brute-force kernels that is N1*N2 per bin).
  * This is the cost the host balances when it shards the job list over GPUs (replaces the "largest jobs first"

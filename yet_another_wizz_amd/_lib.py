@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "yawhip_catalog_device_bytes",
     "yawhip_count_pairs",
     "yawhip_job_work",
+    "yawhip_assign_patches",
 )
 
 
@@ -109,6 +110,7 @@ def load_library() -> ctypes.CDLL:
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
         _i64p, _dp, ctypes.POINTER(_Stats),
     ]
+    lib.yawhip_assign_patches.argtypes = [_vp, ctypes.c_int64, _dp, _dp, _dp, ctypes.c_int32, _dp, _i32p]
     lib.yawhip_job_work.argtypes = [
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _i64p,
     ]
@@ -259,3 +261,16 @@ def job_work(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, threshold
         "yawhip_job_work",
     )
     return work
+
+
+def assign_patches(ctx: Context, x, y, z, centers_xyz) -> np.ndarray:
+    """Run ``yawhip_assign_patches``: index of the nearest centre for every object (int32[n])."""
+    x, y, z = _f64(x), _f64(y), _f64(z)
+    centers = np.ascontiguousarray(centers_xyz, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(len(x), dtype=np.int32)
+    _check(
+        load_library().yawhip_assign_patches(ctx._h, len(x), _ptr(x, _dp), _ptr(y, _dp), _ptr(z, _dp), len(centers),
+                                             _ptr(centers, _dp), _ptr(out, _i32p)),
+        "yawhip_assign_patches",
+    )
+    return out

@@ -933,6 +933,36 @@ hipError_t launch_count_any(bool priv, bool filter, int r, yawhip_ctx *ctx, cons
                   : launch_count_r<W, false, false>(r, ctx, c1, c2, n_slots, n_bins, n_edges, n_items, lds);
 }
 
+// Nearest patch centre of every object (replaces scipy.cluster.vq.vq in assign_patch_centers, catalog.py:229-249):
+// squared distance accumulated x, y, z in that order with separately rounded products and sums, first minimum
+// wins -- the arithmetic of scipy's small-dimension vq loop, so ids are identical including exact ties.
+__global__ __launch_bounds__(256) void k_assign_patches(int64_t n, const double *__restrict__ x, const double *__restrict__ y,
+                                                       const double *__restrict__ z, int n_centers,
+                                                       const double *__restrict__ centers, int32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *c = reinterpret_cast<double *>(lds_raw);  // [n_centers][3]
+    for (int e = threadIdx.x; e < 3 * n_centers; e += blockDim.x) c[e] = centers[e];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double px = x[i], py = y[i], pz = z[i];
+    double best = INFINITY;
+    int best_j = -1;
+    for (int j = 0; j < n_centers; ++j) {
+        const double dx = px - c[3 * j], dy = py - c[3 * j + 1], dz = pz - c[3 * j + 2];
+        const double xx = dx * dx;
+        const double yy = dy * dy;
+        const double zz = dz * dz;
+        const double sxy = xx + yy;
+        const double d = sxy + zz;
+        if (d < best) {
+            best = d;
+            best_j = j;
+        }
+    }
+    out[i] = best_j;
+}
+
 // ---- upload-side kernels: ordering of a catalogue on the device (the sorts themselves: yawhip_sort.hip) ----
 __global__ void k_gather_columns(int64_t n, const uint32_t *__restrict__ perm, const double *__restrict__ sx,
                                  const double *__restrict__ sy, const double *__restrict__ sz, const double *__restrict__ sw,
@@ -1667,6 +1697,48 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }
+    return YAWHIP_OK;
+}
+
+int yawhip_assign_patches(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z, int32_t n_centers,
+                          const double *centers_xyz, int32_t *patch_out) {
+    if (!ctx) return fail(YAWHIP_ERR_INVALID, "yawhip_assign_patches: ctx is NULL");
+    if (n < 0 || n_centers <= 0 || !centers_xyz || (n > 0 && (!x || !y || !z || !patch_out)))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_assign_patches: bad sizes or NULL arrays");
+    if ((size_t)n_centers * 3 * sizeof(double) > (size_t)ctx->lds_limit)
+        return fail(YAWHIP_ERR_INVALID, "too many centres (%d) for the LDS table", n_centers);
+    if (n == 0) return YAWHIP_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *dx = nullptr, *dc = nullptr;
+    int32_t *dout = nullptr;
+    auto cleanup = [&]() {
+        if (dx) (void)hipFree(dx);
+        if (dc) (void)hipFree(dc);
+        if (dout) (void)hipFree(dout);
+    };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dx), (size_t)3 * n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dc), (size_t)3 * n_centers * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&dout), (size_t)n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx + n, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx + 2 * n, z, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dc, centers_xyz, (size_t)3 * n_centers * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        const size_t lds = (size_t)3 * n_centers * sizeof(double);
+        if (lds > 64 * 1024)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_assign_patches), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_assign_patches, dim3((unsigned)((n + 255) / 256)), dim3(256), lds, ctx->stream, n, dx, dx + n, dx + 2 * n,
+                               n_centers, dc, dout);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(patch_out, dout, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "yawhip_assign_patches failed: %s", hipGetErrorString(e));
     return YAWHIP_OK;
 }
 

@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .parallel import local_device_index
 
-__all__ = ["get_context", "device_catalog", "count_fine", "job_work", "release", "default_kernel"]
+__all__ = ["get_context", "device_catalog", "count_fine", "job_work", "assign_patches", "release", "default_kernel"]
 
 _contexts: dict = {}
 default_kernel = "auto"
@@ -91,3 +91,19 @@ def job_work(layout1, layout2, jobs, thresholds, *, kernel: str | None = None, s
     function of the inputs, so every rank derives the same partition."""
     ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis)
     return _lib.job_work(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)
+
+
+def assign_patches(xyz, centers_xyz):
+    """Nearest patch centre per object on the device (``yawhip_assign_patches``), or ``None`` when no
+    GPU / library is available -- patch assignment is catalogue preparation, which the reference does on
+    the host too, so unlike the pair counts it may fall back to scipy there."""
+    try:
+        if _lib.device_count() < 1:
+            return None
+        ctx = get_context()
+    except _lib.YawhipError:
+        return None
+    xyz = np.asarray(xyz, dtype=np.float64)
+    ids = _lib.assign_patches(ctx, np.ascontiguousarray(xyz[:, 0]), np.ascontiguousarray(xyz[:, 1]),
+                              np.ascontiguousarray(xyz[:, 2]), centers_xyz)
+    return ids.astype(np.int64)
