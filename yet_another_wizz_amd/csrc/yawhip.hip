@@ -750,9 +750,11 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
                 p0 = best0 >= c0.pad;
                 p1 = best1 >= c1r.pad;
             }
-            if (__builtin_amdgcn_ballot_w64(p0 || p1) != 0ull) {
-                if (__builtin_amdgcn_ballot_w64(p0) != 0ull) enqueue(i, d0, c0.pad);
-                if (__builtin_amdgcn_ballot_w64(p1) != 0ull) enqueue(i + 1, d1, c1r.pad);
+            // wave masks straight from the compares (a bool that goes through a VGPR costs two VALU per test)
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
+            if ((m0 | m1) != 0ull) {
+                if (m0 != 0ull) enqueue(i, d0, c0.pad);
+                if (m1 != 0ull) enqueue(i + 1, d1, c1r.pad);
             }
         };
         // Slots past the window hold a threshold of 2 (nothing passes), so an odd tail needs no test.
