@@ -505,7 +505,7 @@ struct MergedView {
 //         without a common strip grid: every streamed object then belongs to the item's bin.
 constexpr int BIN_BITS = 6, BIN_MASK = (1 << BIN_BITS) - 1;
 template <int R, bool WEIGHTED, bool NF1, int MODE>
-__global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2, const int32_t *__restrict__ lane_k,
+__device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, const int32_t *__restrict__ lane_k,
                                                      const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
@@ -785,6 +785,30 @@ __global__ __launch_bounds__(MWG) void k_count_merged(MergedView c1, CatView c2,
             if (v) atomicAdd(&out_counts[(int64_t)it.slot * nslots + idx], (unsigned long long)v);
         }
     }
+}
+
+// The kernel proper. With one or two objects per lane the body fits 64 VGPRs without spilling, so the compiler is
+// told to keep 8 waves per SIMD (80 VGPRs / 6 waves otherwise: -9 % time at the headline); with four objects per
+// lane that limit would spill, the default allocation stays.
+#define YAW_COUNT_MERGED_ARGS                                                                                         \
+    MergedView c1, CatView c2, const int32_t *__restrict__ lane_k, const Item *__restrict__ items, int n_bins,        \
+        int n_edges, const double *__restrict__ t, const float *__restrict__ dthr, const double *__restrict__ rwin_k, \
+        int64_t item_base, unsigned long long *__restrict__ out_counts, double *__restrict__ partials,                \
+        const unsigned long long *__restrict__ counters
+#define YAW_COUNT_MERGED_PASS c1, c2, lane_k, items, n_bins, n_edges, t, dthr, rwin_k, item_base, out_counts, partials, counters
+template <int R, bool WEIGHTED, bool NF1, int MODE>
+__global__ __launch_bounds__(MWG) void k_count_merged(YAW_COUNT_MERGED_ARGS) {
+    count_merged_body<R, WEIGHTED, NF1, MODE>(YAW_COUNT_MERGED_PASS);
+}
+template <int R, bool WEIGHTED, bool NF1, int MODE>
+__global__ __launch_bounds__(MWG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_count_merged_occ8(YAW_COUNT_MERGED_ARGS) {
+    count_merged_body<R, WEIGHTED, NF1, MODE>(YAW_COUNT_MERGED_PASS);
+}
+
+template <int R, bool WEIGHTED, bool NF1, int MODE>
+auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
+    if constexpr (R <= 2) return k_count_merged_occ8<R, WEIGHTED, NF1, MODE>;
+    else return k_count_merged<R, WEIGHTED, NF1, MODE>;
 }
 
 // Evaluated pairs per job (na * nb of the job's kept items): the cost the host balances over GPUs.
@@ -1601,7 +1625,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                 const unsigned g = (unsigned)std::min(max_grid, n_items - base);
 #define YAW_LAUNCH_LEAN(RR, WW, NN, MM)                                                                               \
     do {                                                                                                              \
-        auto kern = k_count_merged<RR, WW, NN, MM>;                                                                   \
+        auto kern = pick_count_merged<RR, WW, NN, MM>();                                                              \
         if (lds_merged > 64 * 1024) {                                                                                 \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
