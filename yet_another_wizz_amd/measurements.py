@@ -162,10 +162,12 @@ class PatchLinkage:
         check_patch_conistency(ref_cat, *others)
         patch_ids = list(ref_cat.keys())
         centers, radii = ref_cat.get_centers(), ref_cat.get_radii().data
-        links = {}
-        for pid, center, radius in zip(patch_ids, centers, radii):
-            linked = centers.distance(center).data < (radii + radius + max_angle)
-            links[pid] = set(compress(patch_ids, linked))
+        # all P x P centre separations at once, with the arithmetic of AngularCoordinates.distance
+        # (squares summed over x, y, z, sqrt, 2 asin(r/2)), so the comparison decides exactly as the per-patch loop
+        xyz = centers.to_3d()
+        chord = np.sqrt(((xyz[:, np.newaxis, :] - xyz[np.newaxis, :, :]) ** 2).sum(axis=2))
+        linked = 2.0 * np.arcsin(chord / 2.0) < (radii[np.newaxis, :] + radii[:, np.newaxis] + max_angle)
+        links = {pid: set(compress(patch_ids, row)) for pid, row in zip(patch_ids, linked)}
         new = cls(config, links)
         new.sort_axis = best_sort_axis(centers.to_3d(), np.asarray(ref_cat.get_num_records(), dtype=np.float64))
         return new
