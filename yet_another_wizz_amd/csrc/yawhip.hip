@@ -128,7 +128,8 @@ constexpr int BUILD_WG = 1024;  // threads per workgroup of the item builders
 // per workgroup on each of the two counters. (They are single hot addresses -- with an atomic per wave the
 // builders spent three quarters of their time queueing on them.) Order of the list is irrelevant.
 __device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned long long work, Item *__restrict__ items,
-                                             unsigned long long *__restrict__ counters) {
+                                             unsigned long long *__restrict__ counters, unsigned char *__restrict__ kept) {
+    if (keep && kept) kept[it.pot] = 1;  // weighted runs: this potential item will write its slab
     __shared__ unsigned int s_cnt[BUILD_WG / 64];
     __shared__ unsigned long long s_work[BUILD_WG / 64], s_base;
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(keep);
@@ -159,7 +160,8 @@ template <bool SWEEP>
 __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2, const int32_t *__restrict__ jobs,
                                                      const int64_t *__restrict__ prefix, int n_slots, int n_bins,
                                                      int tile, const double *__restrict__ rwin, int64_t n_pot,
-                                                     Item *__restrict__ items, unsigned long long *__restrict__ counters) {
+                                                     Item *__restrict__ items, unsigned long long *__restrict__ counters,
+                                                     unsigned char *__restrict__ kept) {
     const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     Item it{};
@@ -198,10 +200,10 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
         work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
     }
     if (SWEEP) {
-        append_items(keep, it, work, items, counters);
+        append_items(keep, it, work, items, counters, kept);
     } else {
         if (pot < n_pot) items[pot] = it;  // every potential item is kept
-        append_items(false, it, work, items, counters);
+        append_items(false, it, work, items, counters, nullptr);
         if (pot == 0) counters[0] = (unsigned long long)n_pot;
     }
 }
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, S
                                                             const int32_t *__restrict__ job_runs,
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
                                                             int tile, double rwin, int64_t n_pot,
-                                                            Item *__restrict__ items, unsigned long long *__restrict__ counters) {
+                                                            Item *__restrict__ items, unsigned long long *__restrict__ counters,
+                                                            unsigned char *__restrict__ kept) {
     const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     Item it{};
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, S
             work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
         }
     }
-    append_items(keep, it, work, items, counters);
+    append_items(keep, it, work, items, counters, kept);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -820,14 +823,38 @@ __global__ void k_item_work(const Item *__restrict__ items, const unsigned long 
     atomicAdd(&job_work[it.slot / slots_per_job], (unsigned long long)it.na * (unsigned long long)it.nb);
 }
 
-// Sum the per-item slabs of every (job,bin) slot in item order (deterministic).
-__global__ void k_reduce_partials(const double *__restrict__ partials, const int64_t *__restrict__ prefix,
-                                  int n_slots, int nf, double *__restrict__ out) {
+// Weighted sums: every kept item left a slab of `slab` float64 values at partials[pot]. They are added per output
+// slot in a fixed two-level order -- chunks of REDUCE_CHUNK consecutive potential items, then the chunks of a slot in
+// order -- so the result is bit-reproducible and the reduction is parallel over (chunk, value). Dropped potential
+// items (kept[pot] == 0, their slab is never written) are skipped; kept == nullptr means every item was kept.
+constexpr int REDUCE_CHUNK = 32;
+__global__ void k_reduce_chunks(const double *__restrict__ partials, const unsigned char *__restrict__ kept,
+                                const int64_t *__restrict__ prefix, const int64_t *__restrict__ cprefix, int n_slots,
+                                int slab, double *__restrict__ chunk_sums) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)n_slots * nf) return;
-    const int slot = (int)(idx / nf), j = (int)(idx - (int64_t)slot * nf);
+    const int64_t g = idx / slab;
+    if (g >= cprefix[n_slots]) return;
+    const int e = (int)(idx - g * slab);
+    int lo = 0, hi = n_slots;  // slot = largest s with cprefix[s] <= g
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cprefix[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int64_t p0 = prefix[lo] + (g - cprefix[lo]) * REDUCE_CHUNK;
+    const int64_t p1 = p0 + REDUCE_CHUNK < prefix[lo + 1] ? p0 + REDUCE_CHUNK : prefix[lo + 1];
     double acc = 0.0;
-    for (int64_t it = prefix[slot]; it < prefix[slot + 1]; ++it) acc += partials[it * nf + j];
+    for (int64_t pot = p0; pot < p1; ++pot)
+        if (!kept || kept[pot]) acc += partials[pot * slab + e];
+    chunk_sums[idx] = acc;
+}
+
+__global__ void k_reduce_slots(const double *__restrict__ chunk_sums, const int64_t *__restrict__ cprefix, int n_slots,
+                               int slab, double *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_slots * slab) return;
+    const int slot = (int)(idx / slab), e = (int)(idx - (int64_t)slot * slab);
+    double acc = 0.0;
+    for (int64_t g = cprefix[slot]; g < cprefix[slot + 1]; ++g) acc += chunk_sums[g * slab + e];
     out[idx] = acc;
 }
 
@@ -880,6 +907,9 @@ struct yawhip_ctx {
     DevBuf<unsigned long long> d_counts;
     DevBuf<double> d_sums;
     DevBuf<double> d_partials;
+    DevBuf<double> d_chunk_sums;
+    DevBuf<int64_t> d_cprefix;
+    DevBuf<unsigned char> d_kept;   // weighted runs: 1 for potential items the builder kept
     DevBuf<unsigned long long> d_jobwork;
     yawsort::Workspace sort_ws;  // upload-side sorts
     int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
@@ -1023,12 +1053,32 @@ __global__ void k_gather_bins(int64_t n, const uint32_t *__restrict__ perm, cons
 __global__ void k_strip_index(int64_t n, const double *__restrict__ v, double width, const int64_t *__restrict__ poff,
                               int n_patches, int32_t *__restrict__ gidx, int32_t *__restrict__ lohi) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t g = width > 0.0 ? (int32_t)floor((v[i] + 1.0) / width) : 0;
-    gidx[i] = g;
-    const int p = segment_of(poff, n_patches, i);
-    atomicMin(&lohi[2 * p], g);
-    atomicMax(&lohi[2 * p + 1], g);
+    const bool ok = i < n;
+    int32_t g = 0;
+    int p = -1;
+    if (ok) {
+        g = width > 0.0 ? (int32_t)floor((v[i] + 1.0) / width) : 0;
+        gidx[i] = g;
+        p = segment_of(poff, n_patches, i);
+    }
+    // Objects of a patch are contiguous, so nearly every wave sits inside one patch: reduce there and issue one
+    // atomic pair per wave (one pair per object on 2P addresses cost 97 ms for 10 M objects).
+    const int p0 = __builtin_amdgcn_readfirstlane(p);
+    if (__builtin_amdgcn_ballot_w64(p != p0) == 0ull) {
+        if (p0 < 0) return;  // whole wave past the end
+        int32_t lo = g, hi = g;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off, 64));
+            hi = max(hi, __shfl_xor(hi, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&lohi[2 * p0], lo);
+            atomicMax(&lohi[2 * p0 + 1], hi);
+        }
+    } else if (ok) {  // a wave across a patch boundary (or the ragged end)
+        atomicMin(&lohi[2 * p], g);
+        atomicMax(&lohi[2 * p + 1], g);
+    }
 }
 
 // run id of the object that is i-th in `order` (objects of a patch are contiguous in the input)
@@ -1124,6 +1174,9 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_counts.release();
     ctx->d_sums.release();
     ctx->d_partials.release();
+    ctx->d_chunk_sums.release();
+    ctx->d_cprefix.release();
+    ctx->d_kept.release();
     ctx->d_jobwork.release();
     ctx->sort_ws.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1565,6 +1618,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        unsigned char *kept_flags = nullptr;  // weighted runs of the culling builders: which potential items write a slab
+        if (run_weighted && sweep) {
+            HIP_TRY(ctx->d_kept.reserve((size_t)n_pot));
+            HIP_TRY(hipMemsetAsync(ctx->d_kept.ptr, 0, (size_t)n_pot, ctx->stream));
+            kept_flags = ctx->d_kept.ptr;
+        }
         const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
         if (merged)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream,
@@ -1574,15 +1633,15 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                          c2->d_tiles[tile_idx]},
                                ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_jobs, ctx->d_prefix.ptr, n_jobs, reach,
                                (int)tile, rwin_max, n_pot,
-                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+                               ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
-                               ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr);
+                               ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else
             hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
-                               ctx->d_items.ptr, ctx->d_ctr.ptr);
+                               ctx->d_items.ptr, ctx->d_ctr.ptr, nullptr);
         HIP_TRY(hipGetLastError());
         ++launches;
         // The count kernels are launched over all potential items and return at once for indices beyond the
@@ -1595,8 +1654,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             n_items = (int64_t)ctr[0];
         }
-        if (run_weighted && sweep)  // dropped items leave their slab untouched
-            HIP_TRY(hipMemsetAsync(ctx->d_partials.ptr, 0, sizeof(double) * (size_t)n_pot * slab, ctx->stream));
     }
     if (ctx->job_work_out) {  // cost estimate only: evaluated pairs per job from the item list, no counting
         HIP_TRY(ctx->d_jobwork.reserve((size_t)n_jobs));
@@ -1611,6 +1668,28 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return YAWHIP_OK;
     }
+    // two-level ordered reduction of the weighted slabs (k_reduce_chunks / k_reduce_slots); prefix = first potential
+    // item of every output slot
+    auto reduce_partials = [&](int64_t n_oslots, int64_t values) -> hipError_t {
+        std::vector<int64_t> cprefix((size_t)n_oslots + 1, 0);
+        for (int64_t sl = 0; sl < n_oslots; ++sl)
+            cprefix[(size_t)sl + 1] = cprefix[(size_t)sl] + (prefix[(size_t)sl + 1] - prefix[(size_t)sl] + REDUCE_CHUNK - 1) / REDUCE_CHUNK;
+        const int64_t n_chunks = cprefix[(size_t)n_oslots];
+        hipError_t er = ctx->d_cprefix.reserve((size_t)n_oslots + 1);
+        if (er == hipSuccess) er = ctx->d_chunk_sums.reserve((size_t)std::max<int64_t>(n_chunks, 1) * values);
+        if (er == hipSuccess)
+            er = hipMemcpy(ctx->d_cprefix.ptr, cprefix.data(), sizeof(int64_t) * ((size_t)n_oslots + 1), hipMemcpyHostToDevice);
+        if (er != hipSuccess) return er;
+        const int thr = 256;
+        const bool all_kept = !(run_weighted && sweep);
+        if (n_chunks > 0)
+            hipLaunchKernelGGL(k_reduce_chunks, dim3((unsigned)((n_chunks * values + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                               ctx->d_partials.ptr, all_kept ? nullptr : ctx->d_kept.ptr, ctx->d_prefix.ptr, ctx->d_cprefix.ptr,
+                               (int)n_oslots, (int)values, ctx->d_chunk_sums.ptr);
+        hipLaunchKernelGGL(k_reduce_slots, dim3((unsigned)((n_oslots * values + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                           ctx->d_chunk_sums.ptr, ctx->d_cprefix.ptr, (int)n_oslots, (int)values, ctx->d_sums.ptr);
+        return hipGetLastError();
+    };
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
     if (n_items > 0 && lean) {
         const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
@@ -1664,14 +1743,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (run_weighted) {
             HIP_TRY(launch_lean(true));
             ++launches;
-            const int thr = 256;
-            const int64_t n_oslots = merged ? (int64_t)n_jobs : n_slots;  // slabs are reduced per output slot
-            const int64_t n_red = n_oslots * slab;
-            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_red + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_oslots,
-                               (int)slab, ctx->d_sums.ptr);
-            HIP_TRY(hipGetLastError());
-            ++launches;
+            HIP_TRY(reduce_partials(merged ? (int64_t)n_jobs : n_slots, slab));  // slabs are reduced per output slot
+            launches += 2;
         }
     } else if (n_items > 0) {
         if (run_unweighted) {
@@ -1687,11 +1760,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                                   lds_for(true, priv));
             HIP_TRY(e);
             ++launches;
-            const int thr = 256;
-            hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n_out + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                               ctx->d_partials.ptr, ctx->d_prefix.ptr, (int)n_slots, nf, ctx->d_sums.ptr);
-            HIP_TRY(hipGetLastError());
-            ++launches;
+            HIP_TRY(reduce_partials(n_slots, nf));
+            launches += 2;
         }
     }
     HIP_TRY(hipEventRecord(ctx->evc1, ctx->stream));
