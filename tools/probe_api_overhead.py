@@ -1,7 +1,8 @@
 """Host-side cost of the public entry points (warm: catalogues resident): cProfile of yaw.crosscorrelate."""
 import sys, time, types, cProfile, pstats
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import yet_another_wizz_amd as yaw
 

@@ -3,7 +3,8 @@ random catalogue, RR self count of the randoms -- full sky, 64 patches, 30 bins 
 `1e7 1e8 w`).   python tools/probe_auto.py [n_data] [n_random] [w]"""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import yet_another_wizz_amd as yaw
 from yet_another_wizz_amd import engine
@@ -18,6 +19,8 @@ def cat(seed, m):
     z = rng.uniform(0.1, 1.0, m)
     w = rng.uniform(0.5, 1.5, m) if weighted else None
     return yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=w, patch_centers=centers, degrees=False)
+if os.environ.get("YAW_TILE_R"):
+    engine.get_context().set_option("tile_r", int(os.environ["YAW_TILE_R"]))
 config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=30)
 t0 = time.perf_counter()
 data, rand = cat(101, n), cat(303, nr)

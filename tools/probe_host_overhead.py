@@ -1,7 +1,8 @@
 """Where the host time of one PatchLinkage.count_pairs call goes (10M x 10M headline, one GPU)."""
 import sys, time, types
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import yet_another_wizz_amd as yaw
 from yet_another_wizz_amd import engine, measurements

@@ -2,7 +2,8 @@
 run on its own; the step time of an N-GPU run is the slowest share (+ all-reduce)."""
 import sys, types
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import yet_another_wizz_amd as yaw
 from yet_another_wizz_amd import engine, parallel
