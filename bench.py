@@ -148,9 +148,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the pair-count path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    from yet_another_wizz_amd import parallel
+
+    device = parallel.local_device_index()  # LOCAL_RANK (YAW_AMD_DEVICE lets a rehearsal share one GPU)
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL (backend "nccl") in production; YAW_BENCH_BACKEND=gloo lets several ranks rehearse on ONE GPU
+        backend = os.environ.get("YAW_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     from yet_another_wizz_amd import PatchLinkage, engine
 
@@ -194,9 +202,10 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # whole-job numbers: max time over ranks, sum of per-rank work
-    tens = torch.tensor([elapsed, kernel_ms / max(args.steps, 1)], dtype=torch.float64, device="cuda")
+    stat_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+    tens = torch.tensor([elapsed, kernel_ms / max(args.steps, 1)], dtype=torch.float64, device=stat_dev)
     work = torch.tensor([float(stats.candidate_pairs), float(stats.evaluated_pairs), float(stats.algorithmic_bytes),
-                         float(stats.n_workgroups)], dtype=torch.float64, device="cuda")
+                         float(stats.n_workgroups)], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(tens, op=dist.ReduceOp.MAX)
         dist.all_reduce(work, op=dist.ReduceOp.SUM)
