@@ -1482,7 +1482,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool strips = lean && c1->mx != nullptr && c2->mx != nullptr && c1->strip_width == c2->strip_width &&
                         c1->strip_axis == c2->strip_axis &&
                         (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
-    // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items (DESIGN.md section 7)
+    // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items (DESIGN.md section 8)
     const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1
                      : (ctx->binned_strips && c1->nb > 1 && c2->nb > 1 && n_bins <= BIN_MASK + 1) ? 2 : 0;
     const bool merged = mode != 0;
