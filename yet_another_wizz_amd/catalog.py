@@ -33,6 +33,15 @@ def _check_patch_count(num: int) -> None:
         raise ValueError(f"number of patches must be in range [1, {PATCH_ID_MAX}]")
 
 
+def _stable_argsort_small(keys, num_values: int):
+    """Stable argsort of non-negative integer keys < ``num_values``. numpy sorts 16-bit integers with a
+    radix sort (an order of magnitude faster than the merge sort it uses for int64); the permutation is
+    the same, stable sorts being unique."""
+    if num_values <= np.iinfo(np.uint16).max:
+        return np.argsort(keys.astype(np.uint16), kind="stable")
+    return np.argsort(keys, kind="stable")
+
+
 DEVICE_ASSIGN_MIN = 200_000  # below this the host is as fast as a round trip to the device
 
 
@@ -139,15 +148,19 @@ class Metadata:
                 f"center={self.center.data[0]}, radius={self.radius.data[0]})")
 
     @classmethod
-    def compute(cls, coords: AngularCoordinates, *, weights=None, center: AngularCoordinates | None = None):
+    def compute(cls, coords: AngularCoordinates, *, weights=None, center: AngularCoordinates | None = None, xyz=None):
         """Sum of weights (or N), weighted mean direction, radius = largest separation from the
-        centre (patch.py:103-147)."""
+        centre (patch.py:103-147). ``xyz`` = ``coords.to_3d()`` if the caller has it already (the
+        catalogue computes the unit vectors once): the same values go through the same operations as
+        ``coords.mean`` / ``coords.distance``."""
         if center is not None and len(center) != 1:
             raise ValueError("'center' must be one single coordinate")
         sum_weights = float(len(coords)) if weights is None else float(np.sum(weights))
-        centre = center.copy() if center is not None else coords.mean(weights)
-        return cls(num_records=len(coords), sum_weights=sum_weights, center=centre,
-                   radius=coords.distance(centre).max())
+        if xyz is None:
+            xyz = coords.to_3d()
+        centre = center.copy() if center is not None else AngularCoordinates.from_3d(np.average(xyz, weights=weights, axis=0))
+        radius = AngularDistances.from_3d(np.sqrt(((xyz - centre.to_3d()) ** 2).sum(axis=1))).max()
+        return cls(num_records=len(coords), sum_weights=sum_weights, center=centre, radius=radius)
 
     def to_dict(self) -> dict:
         return dict(num_records=int(self.num_records), sum_weights=float(self.sum_weights),
@@ -277,8 +290,9 @@ class Catalog(Mapping):
         return new
 
     def _setup(self, ra, dec, *, patch_ids, num_patches: int | None = None, weights=None, redshifts=None,
-               patch_centers: AngularCoordinates | None = None, cache_directory=None, stored_meta=None) -> None:
-        """Common initialiser; coordinates in radian."""
+               patch_centers: AngularCoordinates | None = None, cache_directory=None, stored_meta=None,
+               xyz=None) -> None:
+        """Common initialiser; coordinates in radian. ``xyz`` = ``radec_to_xyz(ra, dec)`` if already known."""
         ra = np.asarray_chkfinite(ra, dtype=np.float64)
         dec = np.asarray_chkfinite(dec, dtype=np.float64)
         patch_ids = np.asarray(patch_ids)
@@ -297,12 +311,16 @@ class Catalog(Mapping):
         if np.any(sizes == 0):  # same restriction as the reference (catalog.py:944-947)
             empty = np.flatnonzero(sizes == 0).tolist()
             raise ValueError(f"empty patches are not supported (patch ids {empty})")
-        order = np.argsort(patch_ids, kind="stable")
+        order = _stable_argsort_small(patch_ids, num)
         self._ra, self._dec = ra[order], dec[order]
         self._w = None if weights is None else np.asarray_chkfinite(weights, dtype=np.float64)[order]
         self._z = None if redshifts is None else np.asarray_chkfinite(redshifts, dtype=np.float64)[order]
         self._patch_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-        self._xyz = None
+        # unit vectors: computed once per catalogue (assignment, patch metadata and the device layouts all use
+        # these values -- the exact host numbers the pair predicate runs on)
+        self._xyz = radec_to_xyz(self._ra, self._dec) if xyz is None else tuple(np.asarray(c)[order] for c in xyz)
+        need_meta = not stored_meta or any(pid not in stored_meta for pid in range(num))
+        xyz_rows = np.column_stack(self._xyz) if need_meta else None
         self._layouts: dict = {}
         self._active_layout = None
         self.cache_directory = None if cache_directory is None else Path(cache_directory)
@@ -321,6 +339,7 @@ class Catalog(Mapping):
                     coords,
                     weights=None if self._w is None else self._w[lo:hi],
                     center=None if patch_centers is None else patch_centers[pid],
+                    xyz=xyz_rows[lo:hi],
                 )
             self._patches[pid] = Patch(self, lo, hi, meta)
 
@@ -358,12 +377,13 @@ class Catalog(Mapping):
             centers = kmeans_centers(np.column_stack([x, y, z]), None if weights is None else np.asarray(weights)[::step],
                                      int(patch_num))
         num = None
+        xyz = None
         if centers is not None:
-            x, y, z = radec_to_xyz(ra, dec)
-            patch_ids = nearest_center(np.column_stack([x, y, z]), centers.to_3d())
+            xyz = radec_to_xyz(ra, dec)
+            patch_ids = nearest_center(np.column_stack(xyz), centers.to_3d())
             num = len(centers)
         new = cls._from_columns(ra, dec, patch_ids=patch_ids, num_patches=num, weights=weights, redshifts=redshifts,
-                                patch_centers=centers, cache_directory=None)
+                                patch_centers=centers, cache_directory=None, xyz=xyz)
         if cache_directory is not None:
             new.to_cache(cache_directory, overwrite=overwrite)
         return new
@@ -509,7 +529,7 @@ class Catalog(Mapping):
             keep = np.flatnonzero(bin_idx >= 0)
             patch_of = np.repeat(np.arange(num_patches), np.diff(self._patch_off))
             seg_key = patch_of[keep] * num_bins + bin_idx[keep]
-            order = keep[np.argsort(seg_key, kind="stable")]
+            order = keep[_stable_argsort_small(seg_key, num_patches * num_bins)]
             offsets = np.zeros(num_patches * num_bins + 1, dtype=np.int64)
             np.cumsum(np.bincount(seg_key, minlength=num_patches * num_bins), out=offsets[1:])
             layout = PatchLayout(x[order], y[order], z[order], None if self._w is None else self._w[order], offsets,
