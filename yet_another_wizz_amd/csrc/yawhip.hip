@@ -8,22 +8,22 @@
 //
 // Design (wave64, no MFMA -- K=3 distances are not a contraction and bit parity forbids replacing the
 // predicate by a dot-product form; DESIGN.md section 4 has the details and the measurements):
-//   * catalogues live in HBM as SoA float64 columns x,y,z,(w), sorted by (patch, z-bin) with a CSR
-//     offset table; inside a segment objects are sorted along one coordinate (z unless the caller picks
-//     another axis) -- done once at upload, the ABI leaves the order inside a segment to the library.
-//     A binned catalogue is additionally kept as one sorted run per patch with the bin id per object;
-//   * k_build_items turns the job table into work items (job, bin, lane tile) and, on the SWEEP path,
-//     binary-searches per item the window of the streamed segment that can hold a partner of the tile
-//     (|du| <= sqrt(t_max)), dropping items with an empty window;
-//   * k_count: a 256-thread workgroup keeps 256*R objects of the c2 segment in registers and streams
-//     the window of the c1 segment through LDS (register-staged double buffer, wave-wide broadcast
-//     reads). EXACT: 8 FP64 ops + compare per pair. FILTER/SWEEP: a conservative FP32 dot-product test
-//     first, exact FP64 only for its survivors. Per-lane private LDS histograms, fixed-order reduction,
-//     64-bit integer atomics (unweighted) or per-item slabs summed in item order (weighted);
-//   * k_count_merged: the cross-correlation fast path (binned x unbinned) -- one item streams one window
-//     of the merged run for all bins, float32 only on chip, survivors queued per wave and evaluated 64
-//     at a time from L2-hot float64 data.
-// No floating point atomics anywhere: weighted sums are bit-reproducible run to run.
+//   * catalogues live in HBM as SoA float64 columns x,y,z,(w) in two library-private orders, both made on the
+//     device at upload (yawhip_sort.hip): (patch, z-bin, u) with a CSR offset table, u = the sort axis; and the
+//     strip layout (patch, strip, u) -- strips of a global grid along a second axis, all bins together, bin id
+//     per object -- whose runs can be paired across catalogues by grid index alone;
+//   * k_build_items / k_build_items_strips turn the job table into work items (lane tile of c2) x (window of a
+//     c1 segment or run): one thread per potential item decodes it arithmetically, binary-searches the window
+//     |du| <= sqrt(t_max) and drops empty ones; one atomic per workgroup appends the rest;
+//   * k_count (EXACT / FILTER, non-unit input): 256-thread workgroups, 256*R lane objects in registers, the
+//     c1 segment streamed through LDS; 8 FP64 ops + compare per pair, or a conservative FP32 dot-product test
+//     first and exact FP64 for its survivors. Per-lane private LDS histograms, fixed-order reduction;
+//   * k_count_merged (SWEEP, the default): single-wave workgroups, float32 only on chip (packed v_pk_fma_f32),
+//     survivors queued per wave and evaluated 64 at a time in exact FP64; one item of the cross-correlation
+//     path covers all redshift bins.
+// Unweighted counts: uint32 LDS histograms -> 64-bit integer atomics. Weighted sums: per-item slabs (LDS float64
+// atomics private to one wave) reduced in a fixed two-level order -> bit-reproducible run to run. No floating
+// point atomics in global memory.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (see yet_another_wizz_amd/build.py).
 
 #include <hip/hip_runtime.h>
@@ -106,9 +106,9 @@ constexpr double UNIT_NORM_TOL = 1e-9;
 struct alignas(16) Item {  // one unit of work for a workgroup
     int64_t a0;    // first lane object (c2 side)
     int64_t b0;    // first streamed object (c1 side)
-    int32_t na;    // lane objects (<= 256*R)
+    int32_t na;    // lane objects (<= 256*R, <= 64*R on the SWEEP path)
     int32_t nb;    // streamed objects
-    int32_t slot;  // job * n_bins + bin
+    int32_t slot;  // output slot: job * n_bins + bin, or the job itself on the strip path
     int32_t pot;   // index among all potential items (slab index of weighted partial sums)
 };
 
@@ -120,7 +120,7 @@ struct alignas(16) Item {  // one unit of work for a workgroup
 //                  [umin - rwin, umax + rwin] can satisfy s <= t_max (s >= du^2);
 //                  rwin[k] = sqrt(t_max[k]) * (1 + 1e-12) + 1e-15 absorbs every rounding in
 //                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
-//                  dropped; survivors are appended with one atomic per wave (order is irrelevant).
+//                  dropped; survivors are appended with one atomic per workgroup (order is irrelevant).
 // ------------------------------------------------------------------------------------------------
 constexpr int BUILD_WG = 1024;  // threads per workgroup of the item builders
 
