@@ -472,18 +472,18 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-correlation fast path: c1 binned in redshift, c2 unbinned, unit vectors.
-// The c1 side is read from its *merged* layout: all bins of a patch in one z-sorted run with the
-// bin id kept per object. A work item = (job, lane tile of the c2 patch); it streams the single
-// z-window of the merged c1 patch that can hold partners of the tile, whatever their bin.
+// Culling kernel (SWEEP). Cross-correlation form: c1 binned in redshift, c2 unbinned, unit vectors, both in
+// their strip layouts (runs of (patch, strip), all bins together, bin id per object on the c1 side).
+// A work item = (lane tile: 64*R consecutive objects of one run of c2) x (the window of one partner run of c1
+// that can hold partners of the tile, whatever their bin). One wave = one workgroup = one item.
 //
 // Fast path (all pairs of the window): only float32 lives on chip. Lanes keep the float32 image of
-// their R objects (3R VGPRs); the stream is staged in LDS as 16-byte records (xf, yf, zf, pre-filter
-// threshold of the object's own bin), so per-bin scales cost nothing in the loop: 12 mul/fma +
-// 2 max3 + 1 compare per 256 pairs and streamed object, two objects per trip, next trip prefetched.
-// Each wave owns a contiguous z-chunk of the tile and skips the stage entries outside its own window.
+// their R objects packed in pairs; the stream is staged in LDS 64 objects at a time as 16-byte records
+// (xf, yf, zf, pre-filter threshold of the object's own bin), so per-bin scales cost nothing in the loop:
+// per trip (two streamed objects, R = 2: 256 pairs) 6 v_pk_mul/fma_f32 + 2 v_max + 2 v_cmp, next trip
+// prefetched from LDS. Stage entries outside the wave's own window are skipped (ballot + popcount).
 //
-// Survivors (a few 1e-3 of the window pairs): the owner lane pushes a 4-byte code (r, lane, stage
+// Survivors (the real pairs and a 1e-6 fringe): the owner lane pushes a 4-byte code (r, lane, stage
 // slot) on its wave's queue; when 64 are waiting (or the stage ends) every lane takes one, gathers
 // the two float64 positions from global memory (L2-hot: both were just read by this workgroup) and
 // evaluates the exact predicate -- full lanes, one memory latency per 64 survivors. Hits go to a
