@@ -449,3 +449,70 @@ def test_strip_widths(ctx, weights):
     finally:
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomised_configurations(ctx, seed):
+    """Small random set-ups against the oracle: random footprint (cap around a random direction, sometimes
+    the whole sphere), patch assignment with tiny and empty patches, duplicated objects (equal sort keys and
+    zero separations), random number of bins / edges / scales, strip grid spacing and sort axis, weights on
+    either side, cross and self counts."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.integers(1, 7))
+    B = int(rng.integers(1, 6))
+    n1, n2 = int(rng.integers(50, 3000)), int(rng.integers(50, 3000))
+    cap = rng.choice([0.02, 0.2, 2.0])  # half opening (rad) of the footprint; 2.0 ~ most of the sphere
+    centre = rng.normal(size=3); centre /= np.linalg.norm(centre)
+
+    def sample(n, nb, weighted):
+        v = centre + np.tan(min(cap, 1.5)) * rng.normal(size=(n, 3)) * 0.5
+        v /= np.linalg.norm(v, axis=1)[:, None]
+        if n > 20:  # duplicates: identical positions
+            v[rng.integers(0, n, n // 10)] = v[rng.integers(0, n, n // 10)]
+        ra, dec = np.arctan2(v[:, 1], v[:, 0]) % (2 * np.pi), np.arcsin(np.clip(v[:, 2], -1, 1))
+        patch = rng.integers(0, P, n)
+        if P > 2:
+            patch[patch == 1] = 0          # patch 1 stays empty
+            patch[: min(2, n)] = P - 1     # a patch with (at least) two objects
+        z = rng.uniform(0.0, 1.0, n)
+        w = rng.uniform(0.2, 3.0, n) if weighted else None
+        edges = np.linspace(0.05, 0.95, nb + 1) if nb > 1 else None
+        return oracle.sort_catalog(ra, dec, z, w, patch, P, edges, "right")
+
+    w1, w2 = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    nb2 = B if rng.integers(0, 2) else 1
+    c1, c2 = sample(n1, B, w1), sample(n2, nb2, w2)
+    n_scales = int(rng.integers(1, 4))
+    t = []
+    for k in range(B):
+        lo = np.sort(rng.uniform(0.02, 0.5, n_scales)) * cap * (1 + 0.1 * k)
+        hi = lo * rng.uniform(1.5, 6.0, n_scales)
+        lim = oracle.parse_ang_limits(lo, np.minimum(hi, 3.0))
+        t.append(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)))
+    if len({len(x) for x in t}) != 1:  # keep one edge count per call (the ABI takes a rectangular table)
+        t = [t[0]] * B
+    t = np.stack(t)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P) if rng.random() < 0.8 or p == q], dtype=np.int32)
+    micro = int(rng.choice([0, 1000, 4000, 20000, 300000]))
+    axis = int(rng.integers(0, 3))
+    try:
+        ctx.set_option("strip_width_micro", micro)
+        ctx.set_option("tile_r", int(rng.choice([0, 1, 2, 4])))
+        up = lambda c: _lib.DeviceCatalog(ctx, c["x"], c["y"], c["z"], c["w"], P, c["nb"], c["off"], sort_axis=axis)
+        d1, d2 = up(c1), up(c2)
+        for a, b, da, db in ((c1, c2, d1, d2), (c1, c1, d1, d1)):
+            exp_c, exp_s = oracle.count_jobs(a, b, jobs, t)
+            for kernel in ("sweep", "exact"):
+                counts, sums, _ = _lib.count_pairs(ctx, da, db, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+                assert np.array_equal(counts, exp_c), (seed, kernel)
+                if a["w"] is None and b["w"] is None:
+                    assert np.array_equal(sums, exp_c.astype(np.float64))
+                else:
+                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+            assert np.array_equal(_lib.job_work(ctx, da, db, jobs, t, kernel="exact").sum(),
+                                  _lib.count_pairs(ctx, da, db, jobs, t, kernel="exact")[2].candidate_pairs)
+    finally:
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+        ctx.set_option("tile_r", 0)
