@@ -545,7 +545,11 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
     // Everything the item needs from global memory is requested here, back to back, before the first use:
     // lane objects, the key range of the wave, the first stage of the stream, thresholds (one memory latency).
     const int64_t nb_total = b1 - b0;
+#ifdef YAW_DIAG_SKIP_STREAM
+    const int nstages = 0;  // diagnostics: per-item fixed cost only (wrong counts)
+#else
     const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
+#endif
     constexpr int NPF = (MSTAGE + MWG - 1) / MWG;  // stage slots a thread fills
     struct Raw { double x, y, z; int k; bool in; };
     auto fetch_raw = [&](int64_t i) {  // streamed object i (clamped into the window: unconditional loads)
