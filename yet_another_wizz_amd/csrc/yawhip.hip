@@ -58,6 +58,7 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
+constexpr int SEG_STRIPS_MIN_RUN = 192;  // mean objects per (patch, bin, strip) run from which the per-segment strip layout is built
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
@@ -919,6 +920,25 @@ struct yawhip_ctx {
     int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
 
+struct StripLayout {
+    double *x = nullptr, *y = nullptr, *z = nullptr, *w = nullptr;
+    int32_t *k = nullptr;             // bin id per object (patch-level layout of a binned catalogue)
+    int64_t *off = nullptr;           // [V+1] offsets of the runs
+    std::vector<int64_t> h_off;       // same on the host
+    std::vector<int64_t> h_vbase;     // [G+1] first run of every group
+    std::vector<int64_t> h_slo;       // [G]   global strip index of a group's first run
+    std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
+    int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
+    int64_t n_groups = 0;
+    void release() {
+        for (void *q : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)off, (void *)d_vbase, (void *)d_slo,
+                        (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2]})
+            if (q) (void)hipFree(q);
+        x = y = z = w = nullptr; k = nullptr; off = d_vbase = d_slo = nullptr;
+        d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
+    }
+};
+
 struct yawhip_catalog {
     yawhip_ctx *ctx = nullptr;
     int64_t n = 0;
@@ -929,18 +949,12 @@ struct yawhip_catalog {
     int64_t device_bytes = 0;
     bool unit_norm = true;  // every |a|^2 within UNIT_NORM_TOL of 1 (precondition of the FP32 pre-filter)
     int axis = 2;           // coordinate the segments are sorted by (0 = x, 1 = y, 2 = z)
-    // strip layout (every catalogue): each patch cut into strips of a global grid along a second axis
-    // ("virtual patches"); inside a (patch, strip) run all redshift bins together, sorted along the sort
-    // axis, with the bin id per object for a binned catalogue. The cross-correlation fast path pairs only
-    // strips that are at most sqrt(t_max) apart.
-    double *mx = nullptr, *my = nullptr, *mz = nullptr, *mw = nullptr;
-    int32_t *mk = nullptr;
-    int64_t *moff = nullptr;          // [V+1] offsets of the (patch, strip) runs
-    std::vector<int64_t> h_moff;      // same on the host
-    std::vector<int64_t> h_vbase;     // [P+1] first run of every patch
-    std::vector<int64_t> h_slo;       // [P]   global strip index of a patch's first run
-    std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
-    int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
+    // strip layouts: the objects of every *group* cut into strips of a global grid along a second axis; inside a
+    // (group, strip) run sorted along the sort axis. Partner runs of two catalogues are those whose grid indices
+    // differ by at most sqrt(t_max) / spacing + 1.
+    //   strips: group = patch, all redshift bins together, bin id per object (cross-correlation counts);
+    //   seg:    group = (patch, bin) segment (binned x binned counts of dense catalogues; binned catalogues only).
+    StripLayout strips, seg;
     double strip_width = 0.0;         // grid spacing (chord units); 0 = one run per patch
     int strip_axis = 0;
 };
@@ -1307,33 +1321,36 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         if ((e = hipGetLastError()) != hipSuccess) return bail(e, "gather");
     }
     c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
-    if (c->unit_norm && n > 0) {
-        // Strip layout for the cross-correlation fast path: runs of (patch, strip), all bins together, sorted along
-        // the sort axis inside a run. Strips are cells of a global grid along strip_axis, so that runs of different
-        // catalogues can be paired by their grid index alone.
-        const double width = ctx->strip_width;
-        const int saxis = (sort_axis + 2) % 3;  // z -> y, y -> x, x -> z
-        std::vector<int64_t> h_poff((size_t)n_patches + 1);
-        for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
+    // One strip layout: groups = patches (bins merged, bin id per object) or (patch, bin) segments.
+    const double width = ctx->strip_width;
+    const int saxis = (sort_axis + 2) % 3;  // z -> y, y -> x, x -> z
+    int layout_rc = YAWHIP_OK;
+    auto bail_rc = [&](hipError_t err, const char *what) { layout_rc = bail(err, what); return false; };
+    auto build_layout = [&](StripLayout &L, const int64_t *goff, int n_patches, bool want_bins) -> bool {
+        std::vector<int64_t> h_poff(goff, goff + n_patches + 1);
+        if (poff) (void)hipFree(poff);
+        if (lohi) (void)hipFree(lohi);
+        poff = nullptr;
+        lohi = nullptr;
         std::vector<int32_t> h_lohi((size_t)2 * n_patches);
         for (int p = 0; p < n_patches; ++p) { h_lohi[(size_t)2 * p] = INT32_MAX; h_lohi[(size_t)2 * p + 1] = INT32_MIN; }
         e = hipMalloc(reinterpret_cast<void **>(&poff), (size_t)(n_patches + 1) * sizeof(int64_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&lohi), (size_t)2 * n_patches * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&gidx), (size_t)n * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm2), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run_sorted), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess && !gidx) e = hipMalloc(reinterpret_cast<void **>(&gidx), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess && !perm2) e = hipMalloc(reinterpret_cast<void **>(&perm2), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess && !run) e = hipMalloc(reinterpret_cast<void **>(&run), (size_t)n * sizeof(uint32_t));
+        if (e == hipSuccess && !run_sorted) e = hipMalloc(reinterpret_cast<void **>(&run_sorted), (size_t)n * sizeof(uint32_t));
         if (e == hipSuccess)
             e = hipMemcpyAsync(poff, h_poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync(lohi, h_lohi.data(), (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) return bail(e, "strip tables");
+        if (e != hipSuccess) return bail_rc(e, "strip tables");
         // grid index of every object, first / last occupied strip of every patch
         hipLaunchKernelGGL(k_strip_index, dim3(ngrid), dim3(256), 0, ctx->stream, n, key_of(rx, ry, rz, saxis), width, poff,
                            n_patches, gidx, lohi);
         e = hipMemcpyAsync(h_lohi.data(), lohi, (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return bail(e, "strip index");
+        if (e != hipSuccess) return bail_rc(e, "strip index");
         std::vector<int64_t> vbase((size_t)n_patches + 1, 0), slo((size_t)n_patches, 0);
         for (int p = 0; p < n_patches; ++p) {
             const bool any = h_poff[(size_t)p + 1] > h_poff[(size_t)p];
@@ -1341,57 +1358,69 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
             vbase[(size_t)p + 1] = vbase[(size_t)p] + (any ? (int64_t)h_lohi[(size_t)2 * p + 1] - h_lohi[(size_t)2 * p] + 1 : 0);
         }
         const int64_t n_runs = vbase[(size_t)n_patches];
-        if (n_runs >= (1ll << 31)) return bail(hipErrorInvalidValue, "too many strip runs");
+        if (n_runs >= (1ll << 31)) return bail_rc(hipErrorInvalidValue, "too many strip runs");
         int run_bits = 1;
         while ((1ll << run_bits) < n_runs) ++run_bits;
-        e = hipMalloc(reinterpret_cast<void **>(&c->d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_slo), (size_t)n_patches * sizeof(int64_t));
+        e = hipMalloc(reinterpret_cast<void **>(&L.d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_slo), (size_t)n_patches * sizeof(int64_t));
         if (e == hipSuccess)
-            e = hipMemcpyAsync(c->d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(L.d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
-            e = hipMemcpyAsync(c->d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(L.d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         // order along the sort axis inside every patch, then group by run (unique keys (run, rank): no reliance on
         // the stability of the sort)
         if (e == hipSuccess) e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(rx, ry, rz, sort_axis), poff, n_patches, perm);
-        if (e != hipSuccess) return bail(e, "patch sort");
-        hipLaunchKernelGGL(k_run_of, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, gidx, poff, n_patches, c->d_vbase, c->d_slo, run);
+        if (e != hipSuccess) return bail_rc(e, "patch sort");
+        hipLaunchKernelGGL(k_run_of, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, gidx, poff, n_patches, L.d_vbase, L.d_slo, run);
         e = yawsort::sort_runs(ctx->sort_ws, ctx->stream, n, run, perm, run_bits, perm2, run_sorted);
-        if (e != hipSuccess) return bail(e, "run sort");
-        e = hipMalloc(reinterpret_cast<void **>(&c->mx), col);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->my), col);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->mz), col);
-        if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&c->mw), col);
-        if (e == hipSuccess && n_bins_or_1 > 1) e = hipMalloc(reinterpret_cast<void **>(&c->mk), (size_t)n * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->moff), (size_t)(n_runs + 1) * sizeof(int64_t));
-        if (e != hipSuccess) return bail(e, "strip layout");
-        hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, rx, ry, rz, rw, c->mx, c->my, c->mz, c->mw);
-        if (n_bins_or_1 > 1)
-            hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, n_bins_or_1, c->mk);
+        if (e != hipSuccess) return bail_rc(e, "run sort");
+        e = hipMalloc(reinterpret_cast<void **>(&L.x), col);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.y), col);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
+        if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
+        if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), (size_t)n * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
+        if (e != hipSuccess) return bail_rc(e, "strip layout");
+        hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, rx, ry, rz, rw, L.x, L.y, L.z, L.w);
+        if (want_bins)
+            hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, n_bins_or_1, L.k);
         hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
-                           c->moff);
+                           L.off);
         std::vector<int64_t> voff((size_t)n_runs + 1);
-        e = hipMemcpyAsync(voff.data(), c->moff, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(voff.data(), L.off, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return bail(e, "run offsets");
+        if (e != hipSuccess) return bail_rc(e, "run offsets");
         // small per-run tables the item builder walks on the device
         for (int ri = 0; ri < 3; ++ri) {
             const int64_t tile = (int64_t)MWG << ri;
-            c->h_tiles[ri].assign((size_t)n_runs + 1, 0);
+            L.h_tiles[ri].assign((size_t)n_runs + 1, 0);
             for (int64_t r = 0; r < n_runs; ++r)
-                c->h_tiles[ri][(size_t)r + 1] = c->h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
+                L.h_tiles[ri][(size_t)r + 1] = L.h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
             if (e == hipSuccess)
-                e = hipMemcpyAsync(c->d_tiles[ri], c->h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
+                e = hipMemcpyAsync(L.d_tiles[ri], L.h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
                                    hipMemcpyHostToDevice, ctx->stream);
         }
-        if (e != hipSuccess) return bail(e, "tile tables");
-        c->h_moff = std::move(voff);
-        c->h_vbase = std::move(vbase);
-        c->h_slo = std::move(slo);
+        if (e != hipSuccess) return bail_rc(e, "tile tables");
+        L.h_off = std::move(voff);
+        L.h_vbase = std::move(vbase);
+        L.h_slo = std::move(slo);
+        L.n_groups = n_patches;
+        c->device_bytes += (int64_t)col * (w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) +
+                           (4 * (n_runs + 1) + 2 * (int64_t)n_patches + 1) * (int64_t)sizeof(int64_t);
+            return true;
+    };
+    if (c->unit_norm && n > 0) {
+        // strips are cells of a global grid along strip_axis, so that runs of different catalogues can be paired by
+        // their grid index alone
+        std::vector<int64_t> h_poff((size_t)n_patches + 1);
+        for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
+        if (!build_layout(c->strips, h_poff.data(), n_patches, n_bins_or_1 > 1)) return layout_rc;
+        // the per-segment layout pays for dense binned catalogues only (runs of at least a few lane tiles)
+        if (n_bins_or_1 > 1 && n / std::max<int64_t>(c->strips.h_vbase[(size_t)n_patches] * n_bins_or_1, 1) >= SEG_STRIPS_MIN_RUN)
+            if (!build_layout(c->seg, offsets, (int)nseg, false)) return layout_rc;
         c->strip_width = width;
         c->strip_axis = saxis;
-        c->device_bytes += (int64_t)col * (w ? 4 : 3) + (n_bins_or_1 > 1 ? n * (int64_t)sizeof(int32_t) : 0) +
-                           (4 * (n_runs + 1) + 2 * (int64_t)n_patches + 1) * (int64_t)sizeof(int64_t);
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(e, "finish");
@@ -1408,16 +1437,8 @@ int yawhip_catalog_free(yawhip_catalog *c) {
     if (c->z) (void)hipFree(c->z);
     if (c->w) (void)hipFree(c->w);
     if (c->off) (void)hipFree(c->off);
-    if (c->mx) (void)hipFree(c->mx);
-    if (c->my) (void)hipFree(c->my);
-    if (c->mz) (void)hipFree(c->mz);
-    if (c->mw) (void)hipFree(c->mw);
-    if (c->mk) (void)hipFree(c->mk);
-    if (c->moff) (void)hipFree(c->moff);
-    if (c->d_vbase) (void)hipFree(c->d_vbase);
-    if (c->d_slo) (void)hipFree(c->d_slo);
-    for (int ri = 0; ri < 3; ++ri)
-        if (c->d_tiles[ri]) (void)hipFree(c->d_tiles[ri]);
+    c->strips.release();
+    c->seg.release();
     delete c;
     return YAWHIP_OK;
 }
@@ -1483,7 +1504,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         rwin_max = std::max(rwin_max, std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15);
     // strip pairing pays while a run has few partner runs; for separations far beyond the grid spacing the
     // ordinary (patch, bin) layout is used instead
-    const bool strips = lean && c1->mx != nullptr && c2->mx != nullptr && c1->strip_width == c2->strip_width &&
+    const bool strips = lean && c1->strips.x != nullptr && c2->strips.x != nullptr && c1->strip_width == c2->strip_width &&
                         c1->strip_axis == c2->strip_axis &&
                         (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
     // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items
@@ -1494,7 +1515,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (R == 0) {
         int64_t max_seg = 0;
         if (merged) {  // lanes hold runs of the strip layout: their typical (mean) length decides
-            const int64_t n_runs = c2->h_vbase[(size_t)c2->n_patches];
+            const int64_t n_runs = c2->strips.h_vbase[(size_t)c2->n_patches];
             max_seg = c2->n / std::max<int64_t>(n_runs, 1);
         } else {
             for (int j = 0; j < n_jobs; ++j)
@@ -1527,16 +1548,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         reach = width > 0.0 ? (int)std::floor(rwin_max / width + 1e-6) + 1 : 0;
         prefix.resize((size_t)n_jobs + 1);
         job_runs.assign((size_t)2 * n_jobs, 0);
-        const std::vector<int64_t> &tiles = c2->h_tiles[tile_idx];
+        const std::vector<int64_t> &tiles = c2->strips.h_tiles[tile_idx];
         for (int j = 0; j < n_jobs; ++j) {
             const int p = jobs[2 * j], q = jobs[2 * j + 1];
             prefix[(size_t)j] = n_items;
             // strips of q whose grid index lies within `reach` of the strips patch p occupies
-            const int64_t cnt1 = c1->h_vbase[(size_t)p + 1] - c1->h_vbase[(size_t)p], lo1 = c1->h_slo[(size_t)p];
-            const int64_t cnt2 = c2->h_vbase[(size_t)q + 1] - c2->h_vbase[(size_t)q], lo2 = c2->h_slo[(size_t)q];
+            const int64_t cnt1 = c1->strips.h_vbase[(size_t)p + 1] - c1->strips.h_vbase[(size_t)p], lo1 = c1->strips.h_slo[(size_t)p];
+            const int64_t cnt2 = c2->strips.h_vbase[(size_t)q + 1] - c2->strips.h_vbase[(size_t)q], lo2 = c2->strips.h_slo[(size_t)q];
             const int64_t s_lo = std::max<int64_t>(lo1 - reach - lo2, 0), s_hi = std::min<int64_t>(lo1 + cnt1 - 1 + reach - lo2, cnt2 - 1);
             if (cnt1 > 0 && s_hi >= s_lo) {
-                const int64_t r0 = c2->h_vbase[(size_t)q] + s_lo;
+                const int64_t r0 = c2->strips.h_vbase[(size_t)q] + s_lo;
                 job_runs[(size_t)2 * j] = (int32_t)s_lo;
                 job_runs[(size_t)2 * j + 1] = (int32_t)(s_hi - s_lo + 1);
                 n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * (2 * reach + 1);
@@ -1631,10 +1652,10 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
         if (merged)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream,
-                               StripView{key_of(c1->mx, c1->my, c1->mz, c1->axis), c1->moff, c1->d_vbase, c1->d_slo,
-                                         c1->d_tiles[tile_idx]},
-                               StripView{key_of(c2->mx, c2->my, c2->mz, c2->axis), c2->moff, c2->d_vbase, c2->d_slo,
-                                         c2->d_tiles[tile_idx]},
+                               StripView{key_of(c1->strips.x, c1->strips.y, c1->strips.z, c1->axis), c1->strips.off, c1->strips.d_vbase, c1->strips.d_slo,
+                                         c1->strips.d_tiles[tile_idx]},
+                               StripView{key_of(c2->strips.x, c2->strips.y, c2->strips.z, c2->axis), c2->strips.off, c2->strips.d_vbase, c2->strips.d_slo,
+                                         c2->strips.d_tiles[tile_idx]},
                                ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_jobs, ctx->d_prefix.ptr, n_jobs, reach,
                                (int)tile, rwin_max, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
@@ -1696,12 +1717,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     };
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
     if (n_items > 0 && lean) {
-        const MergedView mv = merged ? MergedView{c1->mx, c1->my, c1->mz, c1->mw, c1->mk}
+        const MergedView mv = merged ? MergedView{c1->strips.x, c1->strips.y, c1->strips.z, c1->strips.w, c1->strips.k}
                                      : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
-        const CatView lanes = merged ? CatView{c2->mx, c2->my, c2->mz, c2->mw, c2->moff, 1,
-                                               key_of(c2->mx, c2->my, c2->mz, c2->axis), c2->axis}
+        const CatView lanes = merged ? CatView{c2->strips.x, c2->strips.y, c2->strips.z, c2->strips.w, c2->strips.off, 1,
+                                               key_of(c2->strips.x, c2->strips.y, c2->strips.z, c2->axis), c2->axis}
                                      : view_of(c2);
-        const int32_t *lane_k = mode == 2 ? c2->mk : nullptr;
+        const int32_t *lane_k = mode == 2 ? c2->strips.k : nullptr;
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
