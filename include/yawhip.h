@@ -79,7 +79,9 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx);
  *   "strip_width_micro" spacing, in 1e-6 chord units, of the strip grid of catalogues uploaded afterwards
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
  *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
- *   "binned_strips"     1: binned x binned counts also use the strip layout (default 0)
+ *   "seg_strips"        binned x binned counts use the per-(patch, bin) strip layouts of dense catalogues (default 1)
+ *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 192)
+ *   "binned_strips"     1: binned x binned counts use the merged-bin strip layout instead (default 0)
  *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 

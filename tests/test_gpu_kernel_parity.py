@@ -516,3 +516,49 @@ def test_randomised_configurations(ctx, seed):
     finally:
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+def test_segment_strip_layout_path(ctx, weights):
+    """Binned x binned counts on the per-(patch, bin) strip layouts (built for dense catalogues; forced here
+    with ``seg_strips_min_run`` = 1): cross and self counts, several tile sizes and grid spacings, against
+    the oracle and against the ordinary per-bin items (``seg_strips`` = 0): identical counts (the saving in
+    evaluated pairs only shows for dense catalogues)."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(97)
+    P, B = 4, 5
+    c1 = _random_catalog(rng, 40000, P, B, weights[0] == "w", dense_box=6.0)
+    c2 = _random_catalog(rng, 50000, P, B, weights[1] == "w", dense_box=6.0)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    t = []
+    for k in range(B):
+        lim = oracle.parse_ang_limits(np.array([1.0, 4.0]) * np.pi / 10800, np.array([4.0, 10.0 + 2 * k]) * np.pi / 10800)
+        t.append(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)))
+    t = np.stack(t)
+    try:
+        ctx.set_option("seg_strips_min_run", 1)
+        evaluated = {}
+        for micro in (3000, 8000):
+            ctx.set_option("strip_width_micro", micro)
+            d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+            for a, b, da, db in ((c1, c2, d1, d2), (c2, c2, d2, d2)):
+                exp_c, exp_s = oracle.count_jobs(a, b, jobs, t)
+                assert exp_c.sum() > 10000
+                for seg in (1, 0):
+                    ctx.set_option("seg_strips", seg)
+                    for tile_r in (0, 1, 4):
+                        ctx.set_option("tile_r", tile_r)
+                        counts, sums, st = _lib.count_pairs(ctx, da, db, jobs, t, kernel="sweep", want_counts=True, want_sums=True)
+                        assert np.array_equal(counts, exp_c), (micro, seg, tile_r)
+                        if weights == "ww":
+                            np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+                        evaluated[(micro, a is c1, seg, tile_r)] = st.evaluated_pairs
+                    work = _lib.job_work(ctx, da, db, jobs, t, kernel="sweep")
+                    # (a weighted call that also returns counts runs the kernel twice)
+                    assert work.sum() * (2 if weights == "ww" else 1) == evaluated[(micro, a is c1, seg, 4)]
+    finally:
+        ctx.set_option("seg_strips_min_run", 192)
+        ctx.set_option("seg_strips", 1)
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+        ctx.set_option("tile_r", 0)

@@ -58,7 +58,7 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
-constexpr int SEG_STRIPS_MIN_RUN = 192;  // mean objects per (patch, bin, strip) run from which the per-segment strip layout is built
+constexpr int SEG_STRIPS_MIN_RUN = 192;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
@@ -897,6 +897,8 @@ struct yawhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
     int binned_strips = 0;   // 1: binned x binned counts use the strip layout too (k_count_merged MODE 2)
+    int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
+    int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
@@ -1220,6 +1222,15 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->strip_width = (double)value * 1e-6;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "seg_strips_min_run")) {
+        if (value < 1) return fail(YAWHIP_ERR_INVALID, "seg_strips_min_run must be >= 1");
+        ctx->seg_min_run = (int)std::min<int64_t>(value, INT32_MAX);
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "seg_strips")) {
+        ctx->seg_strips = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "binned_strips")) {
         ctx->binned_strips = value != 0;
         return YAWHIP_OK;
@@ -1416,8 +1427,8 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         std::vector<int64_t> h_poff((size_t)n_patches + 1);
         for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
         if (!build_layout(c->strips, h_poff.data(), n_patches, n_bins_or_1 > 1)) return layout_rc;
-        // the per-segment layout pays for dense binned catalogues only (runs of at least a few lane tiles)
-        if (n_bins_or_1 > 1 && n / std::max<int64_t>(c->strips.h_vbase[(size_t)n_patches] * n_bins_or_1, 1) >= SEG_STRIPS_MIN_RUN)
+        // per-segment layout of a binned catalogue (used when the lane side of a binned x binned count is dense)
+        if (n_bins_or_1 > 1)
             if (!build_layout(c->seg, offsets, (int)nseg, false)) return layout_rc;
         c->strip_width = width;
         c->strip_axis = saxis;
@@ -1508,15 +1519,24 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                         c1->strip_axis == c2->strip_axis &&
                         (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
     // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items
+    // mode 3: binned x binned on the per-segment strip layouts (built at upload for dense catalogues only): ordinary
+    // (job, bin) items whose lane tiles and windows come from (patch, bin, strip) runs
+    // -- it pays when the lane side is dense: runs of at least a few lane tiles per (patch, bin, strip)
+    const bool seg_ok = strips && c1->seg.x != nullptr && c2->seg.x != nullptr && c1->nb == n_bins && c2->nb == n_bins && ctx->seg_strips &&
+                        c2->n / std::max<int64_t>(c2->seg.h_vbase[(size_t)c2->seg.n_groups], 1) >= ctx->seg_min_run;
     const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1
-                     : (ctx->binned_strips && c1->nb > 1 && c2->nb > 1 && n_bins <= BIN_MASK + 1) ? 2 : 0;
-    const bool merged = mode != 0;
+                     : (ctx->binned_strips && c1->nb > 1 && c2->nb > 1 && n_bins <= BIN_MASK + 1) ? 2 : (seg_ok ? 3 : 0);
+    const bool merged = mode == 1 || mode == 2;   // one item covers all bins, output slot = job
+    const bool strip_items = mode != 0;           // items come from strip runs (k_build_items_strips)
+    const StripLayout &sl1 = mode == 3 ? c1->seg : c1->strips, &sl2 = mode == 3 ? c2->seg : c2->strips;
     int R = ctx->tile_r;
     if (R == 0) {
         int64_t max_seg = 0;
-        if (merged) {  // lanes hold runs of the strip layout: their typical (mean) length decides
-            const int64_t n_runs = c2->strips.h_vbase[(size_t)c2->n_patches];
+        if (strip_items) {  // lanes hold runs of a strip layout: their typical (mean) length decides
+            const int64_t n_runs = sl2.h_vbase[(size_t)sl2.n_groups];
             max_seg = c2->n / std::max<int64_t>(n_runs, 1);
+            if (mode == 3) max_seg = std::max<int64_t>(max_seg, 4 * MWG * 2);  // at least two objects per lane: per-bin runs are
+                                                                                // sparse, the per-item cost outweighs the wider window
         } else {
             for (int j = 0; j < n_jobs; ++j)
                 for (int k = 0; k < (c2->nb == 1 ? 1 : n_bins); ++k) max_seg = std::max(max_seg, seg_len(c2, jobs[2 * j + 1], k));
@@ -1542,28 +1562,39 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
     int reach = 0;
     const int tile_idx = R == 1 ? 0 : (R == 2 ? 1 : 2);
-    if (merged) {
+    // strip paths: the builder's job table. Modes 1/2: the jobs themselves (groups = patches); mode 3: one pseudo job
+    // per (job, bin) between the segments (p, k) and (q, k) (groups = segments), numbered like the output slots.
+    std::vector<int32_t> sjobs;
+    const int64_t n_sjobs = mode == 3 ? n_slots : (int64_t)n_jobs;
+    if (strip_items) {
         const double width = c1->strip_width;
         // |dv| <= rwin_max  ->  grid indices differ by at most floor(rwin_max / width) + 1
         reach = width > 0.0 ? (int)std::floor(rwin_max / width + 1e-6) + 1 : 0;
-        prefix.resize((size_t)n_jobs + 1);
-        job_runs.assign((size_t)2 * n_jobs, 0);
-        const std::vector<int64_t> &tiles = c2->strips.h_tiles[tile_idx];
-        for (int j = 0; j < n_jobs; ++j) {
-            const int p = jobs[2 * j], q = jobs[2 * j + 1];
+        sjobs.resize((size_t)2 * n_sjobs);
+        for (int j = 0; j < n_jobs; ++j)
+            for (int k = 0; k < (mode == 3 ? n_bins : 1); ++k) {
+                const int64_t sj = mode == 3 ? (int64_t)j * n_bins + k : j;
+                sjobs[(size_t)2 * sj] = mode == 3 ? jobs[2 * j] * n_bins + k : jobs[2 * j];
+                sjobs[(size_t)2 * sj + 1] = mode == 3 ? jobs[2 * j + 1] * n_bins + k : jobs[2 * j + 1];
+            }
+        prefix.resize((size_t)n_sjobs + 1);
+        job_runs.assign((size_t)2 * n_sjobs, 0);
+        const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
+        for (int64_t j = 0; j < n_sjobs; ++j) {
+            const int p = sjobs[(size_t)2 * j], q = sjobs[(size_t)2 * j + 1];
             prefix[(size_t)j] = n_items;
-            // strips of q whose grid index lies within `reach` of the strips patch p occupies
-            const int64_t cnt1 = c1->strips.h_vbase[(size_t)p + 1] - c1->strips.h_vbase[(size_t)p], lo1 = c1->strips.h_slo[(size_t)p];
-            const int64_t cnt2 = c2->strips.h_vbase[(size_t)q + 1] - c2->strips.h_vbase[(size_t)q], lo2 = c2->strips.h_slo[(size_t)q];
+            // strips of q whose grid index lies within `reach` of the strips group p occupies
+            const int64_t cnt1 = sl1.h_vbase[(size_t)p + 1] - sl1.h_vbase[(size_t)p], lo1 = sl1.h_slo[(size_t)p];
+            const int64_t cnt2 = sl2.h_vbase[(size_t)q + 1] - sl2.h_vbase[(size_t)q], lo2 = sl2.h_slo[(size_t)q];
             const int64_t s_lo = std::max<int64_t>(lo1 - reach - lo2, 0), s_hi = std::min<int64_t>(lo1 + cnt1 - 1 + reach - lo2, cnt2 - 1);
             if (cnt1 > 0 && s_hi >= s_lo) {
-                const int64_t r0 = c2->strips.h_vbase[(size_t)q] + s_lo;
+                const int64_t r0 = sl2.h_vbase[(size_t)q] + s_lo;
                 job_runs[(size_t)2 * j] = (int32_t)s_lo;
                 job_runs[(size_t)2 * j + 1] = (int32_t)(s_hi - s_lo + 1);
                 n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * (2 * reach + 1);
             }
         }
-        prefix[(size_t)n_jobs] = n_items;
+        prefix[(size_t)n_sjobs] = n_items;
     } else {
         prefix.resize((size_t)n_slots + 1);
     }
@@ -1571,9 +1602,9 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     for (int j = 0; j < n_jobs; ++j) {
         for (int k = 0; k < n_bins; ++k) {
             const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
-            if (!merged) prefix[(size_t)j * n_bins + k] = n_items;
+            if (!strip_items) prefix[(size_t)j * n_bins + k] = n_items;
             if (n1 > 0 && n2 > 0) {
-                if (!merged) n_items += (n2 + tile - 1) / tile;
+                if (!strip_items) n_items += (n2 + tile - 1) / tile;
                 cand += n1 * n2;
             }
         }
@@ -1581,7 +1612,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         for (int k = 0; k < c1->nb; ++k) abytes += seg_len(c1, jobs[2 * j], k) * obj_bytes1;
         for (int k = 0; k < c2->nb; ++k) abytes += seg_len(c2, jobs[2 * j + 1], k) * obj_bytes2;
     }
-    if (!merged) prefix[(size_t)n_pslots] = n_items;
+    if (!strip_items) prefix[(size_t)n_pslots] = n_items;
     const int64_t slab = merged ? (int64_t)n_bins * nf : nf;  // float64 values per item of the weighted slab
 
     const bool want_counts = fine_counts != nullptr;
@@ -1589,7 +1620,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool run_weighted = weighted && want_sums;
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
-    HIP_TRY(ctx->d_jobs.reserve((size_t)4 * n_jobs));
+    HIP_TRY(ctx->d_jobs.reserve((size_t)4 * std::max<int64_t>(n_jobs, n_sjobs)));
     HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
     HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
@@ -1614,10 +1645,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
     HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
-    HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    if (merged)
-        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_jobs, job_runs.data(), sizeof(int32_t) * 2 * n_jobs,
+    if (strip_items) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, sjobs.data(), sizeof(int32_t) * 2 * n_sjobs, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, job_runs.data(), sizeof(int32_t) * 2 * n_sjobs,
                                hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
+    }
     HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
                            ctx->stream));
     HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
@@ -1650,15 +1684,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             kept_flags = ctx->d_kept.ptr;
         }
         const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
-        if (merged)
+        if (strip_items)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream,
-                               StripView{key_of(c1->strips.x, c1->strips.y, c1->strips.z, c1->axis), c1->strips.off, c1->strips.d_vbase, c1->strips.d_slo,
-                                         c1->strips.d_tiles[tile_idx]},
-                               StripView{key_of(c2->strips.x, c2->strips.y, c2->strips.z, c2->axis), c2->strips.off, c2->strips.d_vbase, c2->strips.d_slo,
-                                         c2->strips.d_tiles[tile_idx]},
-                               ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_jobs, ctx->d_prefix.ptr, n_jobs, reach,
-                               (int)tile, rwin_max, n_pot,
-                               ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
+                               StripView{key_of(sl1.x, sl1.y, sl1.z, c1->axis), sl1.off, sl1.d_vbase, sl1.d_slo, sl1.d_tiles[tile_idx]},
+                               StripView{key_of(sl2.x, sl2.y, sl2.z, c2->axis), sl2.off, sl2.d_vbase, sl2.d_slo, sl2.d_tiles[tile_idx]},
+                               ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, ctx->d_prefix.ptr, (int)n_sjobs, reach,
+                               (int)tile, rwin_max, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
@@ -1673,7 +1704,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         // number the builder kept (device counter): no host round trip between the two kernels.
         HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
         n_items = n_pot;
-        if (merged) {
+        if (strip_items) {
             // The strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
             // dispatching workgroups that exit at once (measured, 10M x 10M), more than this round trip costs.
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1717,12 +1748,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     };
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
     if (n_items > 0 && lean) {
-        const MergedView mv = merged ? MergedView{c1->strips.x, c1->strips.y, c1->strips.z, c1->strips.w, c1->strips.k}
-                                     : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
-        const CatView lanes = merged ? CatView{c2->strips.x, c2->strips.y, c2->strips.z, c2->strips.w, c2->strips.off, 1,
-                                               key_of(c2->strips.x, c2->strips.y, c2->strips.z, c2->axis), c2->axis}
-                                     : view_of(c2);
-        const int32_t *lane_k = mode == 2 ? c2->strips.k : nullptr;
+        const MergedView mv = strip_items ? MergedView{sl1.x, sl1.y, sl1.z, sl1.w, merged ? sl1.k : nullptr}
+                                          : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
+        const CatView lanes = strip_items ? CatView{sl2.x, sl2.y, sl2.z, sl2.w, sl2.off, 1, key_of(sl2.x, sl2.y, sl2.z, c2->axis), c2->axis}
+                                          : view_of(c2);
+        const int32_t *lane_k = mode == 2 ? sl2.k : nullptr;
+        const int kmode = merged ? mode : 0;  // kernel form: per-bin items (0) also serve the per-segment strip layouts
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
@@ -1745,7 +1776,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     } while (0)
 #define YAW_LAUNCH_LEAN_M(WW, NN)                                                                                     \
     do {                                                                                                              \
-        if (mode == 1) YAW_LAUNCH_LEAN_R(WW, NN, 1); else if (mode == 2) YAW_LAUNCH_LEAN_R(WW, NN, 2); else YAW_LAUNCH_LEAN_R(WW, NN, 0); \
+        if (kmode == 1) YAW_LAUNCH_LEAN_R(WW, NN, 1); else if (kmode == 2) YAW_LAUNCH_LEAN_R(WW, NN, 2); else YAW_LAUNCH_LEAN_R(WW, NN, 0); \
     } while (0)
                 const bool nf1 = nf == 1;
                 if (wgt) {
