@@ -80,7 +80,7 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx);
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
  *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
  *   "seg_strips"        binned x binned counts use the per-(patch, bin) strip layouts of dense catalogues (default 1)
- *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 192)
+ *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 40)
  *   "binned_strips"     1: binned x binned counts use the merged-bin strip layout instead (default 0)
  *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);

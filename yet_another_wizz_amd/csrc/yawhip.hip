@@ -58,7 +58,7 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
-constexpr int SEG_STRIPS_MIN_RUN = 192;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
+constexpr int SEG_STRIPS_MIN_RUN = 40;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
