@@ -81,7 +81,6 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx);
  *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
  *   "seg_strips"        binned x binned counts use the per-(patch, bin) strip layouts of dense catalogues (default 1)
  *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 40)
- *   "binned_strips"     1: binned x binned counts use the merged-bin strip layout instead (default 0)
  *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 

@@ -352,57 +352,6 @@ def test_wide_angles_and_ragged_tiles(ctx, kernel):
 
 
 @pytest.mark.parametrize("weights", ["uu", "ww"])
-@pytest.mark.parametrize("n_bins", [3, 64, 65])
-def test_both_sides_binned_strip_path(ctx, weights, n_bins):
-    """Binned x binned counts (autocorrelation DD/DR/RR, RR/RD of a cross-correlation) on the strip
-    layout (opt-in, ctx option ``binned_strips``): lanes carry bin ids, a pair counts only inside its own bin. 64 bins is the most the
-    in-threshold bin tag holds; 65 falls back to ordinary (job, bin) items. Includes the self count
-    (same handle on both sides) and thresholds beyond 90 degrees for some bins."""
-    from yet_another_wizz_amd import _lib
-
-    rng = np.random.default_rng(4321 + n_bins)
-    P, B = 4, n_bins
-    c1 = _random_catalog(rng, 20000, P, B, weights[0] == "w", dense_box=5.0)
-    c2 = _random_catalog(rng, 26000, P, B, weights[1] == "w", dense_box=5.0)
-    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
-    t = []
-    for k in range(B):
-        hi = (10.0 + k) * np.pi / 10800 if k % 7 else np.deg2rad(95.0 + k)  # a few bins with a huge outer edge
-        lim = oracle.parse_ang_limits(np.array([1.0]) * np.pi / 10800, np.array([hi]))
-        t.append(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)))
-    t = np.stack(t)
-    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
-    ctx.set_option("binned_strips", 1)
-    try:
-        _both_binned_checks(ctx, c1, c2, d1, d2, jobs, t, B, weights)
-    finally:
-        ctx.set_option("binned_strips", 0)
-        ctx.set_option("tile_r", 0)
-
-
-def _both_binned_checks(ctx, c1, c2, d1, d2, jobs, t, B, weights):
-    from yet_another_wizz_amd import _lib
-
-    for a, b, da, db in ((c1, c2, d1, d2), (c1, c1, d1, d1)):
-        exp_c, exp_s = oracle.count_jobs(a, b, jobs, t)
-        assert exp_c.sum() > 10000
-        for tsel in (slice(None), [k for k in range(B) if k % 7]):  # with / without the wide bins (strip pairing on)
-            tt, ec, es = t.copy(), exp_c.copy(), exp_s.copy()
-            if not isinstance(tsel, slice):
-                wide = [k for k in range(B) if k % 7 == 0]
-                tt[wide] = tt[1]
-                ec2, es2 = oracle.count_jobs(a, b, jobs, tt)
-                ec, es = ec2, es2
-            for tile_r in (0, 1, 4):
-                ctx.set_option("tile_r", tile_r)
-                counts, sums, st = _lib.count_pairs(ctx, da, db, jobs, tt, kernel="sweep", want_counts=True, want_sums=True)
-                assert st.kernel_used == _lib.KERNEL_SWEEP
-                assert np.array_equal(counts, ec), (tile_r, isinstance(tsel, slice))
-                if weights == "ww":
-                    np.testing.assert_allclose(sums, es, rtol=RTOL_W, atol=0)
-
-
-@pytest.mark.parametrize("weights", ["uu", "ww"])
 def test_strip_widths(ctx, weights):
     """The cross-correlation path cuts patches into strips of a global grid and pairs only strips
     within reach. Any grid spacing (also none, and different spacings on the two sides, which

@@ -500,24 +500,19 @@ struct MergedView {
     const int32_t *k;             // bin id per object
 };
 
-// MODE 1: the cross-correlation path described above (c2 unbinned).
-// MODE 2: both sides binned (every count of an autocorrelation, RR/RD of a cross-correlation): the lane
-//         objects carry a bin id too and a pair must agree in it. The streamed object's bin id travels
-//         in the low 6 bits of its pre-filter threshold (set on the host, rounding stays conservative), so
-//         the loop pays one integer compare per pair and the LDS record stays 16 bytes.
-// MODE 0: the same machinery on ordinary (job, bin, tile) items of the (patch, bin) layout, for catalogues
-//         without a common strip grid: every streamed object then belongs to the item's bin.
-constexpr int BIN_BITS = 6, BIN_MASK = (1 << BIN_BITS) - 1;
-template <int R, bool WEIGHTED, bool NF1, int MODE>
-__device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, const int32_t *__restrict__ lane_k,
-                                                     const Item *__restrict__ items,
+// MERGED = true:  the cross-correlation form described above (c1 binned, c2 unbinned, strip layouts, one item for
+//                 all bins).
+// MERGED = false: per-bin items (job, bin, tile): every streamed object belongs to the item's bin. Serves the
+//                 binned x binned counts of an autocorrelation -- on the per-(patch, bin) strip layouts when the lane
+//                 side is dense enough, else on the plain (patch, bin, u) layout -- and everything without a common
+//                 strip grid.
+template <int R, bool WEIGHTED, bool NF1, bool MERGED>
+__device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
                                                      int64_t item_base, unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials,
                                                      const unsigned long long *__restrict__ counters) {
-    constexpr bool MERGED = MODE != 0;
-    constexpr bool LB = MODE == 2;  // lanes carry bin ids
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NHIST = WEIGHTED ? MWG / 64 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -565,13 +560,11 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
         return ObjF{(float)o.x, (float)o.y, (float)o.z, o.in ? dth[o.k] : 2.0f};
     };
     double lx[R], ly[R], lz[R];
-    int lk[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t i = wa0 + (int64_t)r * 64 + lane;
         const int64_t ic = i < a_end ? i : a0;  // padded lanes read a valid object
         lx[r] = c2.x[ic]; ly[r] = c2.y[ic]; lz[r] = c2.z[ic];
-        lk[r] = LB ? lane_k[ic] : 0;
     }
     int64_t wa1 = wa0 + 64 * R;
     if (wa1 > a_end) wa1 = a_end;
@@ -594,11 +587,9 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
     __syncthreads();
 
     float fx[R], fy[R], fz[R];
-    int kl[R];  // bin of the lane objects (MODE 2)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const bool ok = wa0 + (int64_t)r * 64 + lane < a_end;
-        kl[r] = (LB && ok) ? lk[r] : -1;
         fx[r] = ok ? (float)lx[r] : __builtin_nanf("");  // padded lane: dot = NaN fails every comparison (thresholds
                                                           // are <= 0 for separations >= 90 degrees, so 0 would pass)
         fy[r] = ok ? (float)ly[r] : 0.f;
@@ -695,10 +686,9 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
         };
         // Owner lanes of the survivors of stage slot i push their code on the wave's queue.
         auto enqueue = [&](int i, const float (&d)[R], float dmin) {
-            const int kb = __float_as_int(dmin) & BIN_MASK;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const bool pass = d[r] >= dmin && (!LB || kl[r] == kb);
+                const bool pass = d[r] >= dmin;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                 if (m == 0ull) continue;  // uniform
                 const int cnt = __popcll(m);
@@ -740,24 +730,13 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
                 d0[r] = (r & 1) ? e0[r >> 1].y : e0[r >> 1].x;
                 d1[r] = (r & 1) ? e1[r >> 1].y : e1[r >> 1].x;
             }
-            bool p0 = false, p1 = false;
-            if (LB) {
-                const int kb0 = __float_as_int(c0.pad) & BIN_MASK, kb1 = __float_as_int(c1r.pad) & BIN_MASK;
+            float best0 = d0[0], best1 = d1[0];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    p0 |= (d0[r] >= c0.pad) & (kl[r] == kb0);
-                    p1 |= (d1[r] >= c1r.pad) & (kl[r] == kb1);
-                }
-            } else {
-                float best0 = d0[0], best1 = d1[0];
-#pragma unroll
-                for (int r = 1; r < R; ++r) {
-                    best0 = fmaxf(best0, d0[r]);
-                    best1 = fmaxf(best1, d1[r]);
-                }
-                p0 = best0 >= c0.pad;
-                p1 = best1 >= c1r.pad;
+            for (int r = 1; r < R; ++r) {
+                best0 = fmaxf(best0, d0[r]);
+                best1 = fmaxf(best1, d1[r]);
             }
+            const bool p0 = best0 >= c0.pad, p1 = best1 >= c1r.pad;
             // wave masks straight from the compares (a bool that goes through a VGPR costs two VALU per test)
             const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0), m1 = __builtin_amdgcn_ballot_w64(p1);
             if ((m0 | m1) != 0ull) {
@@ -799,24 +778,24 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
 // told to keep 8 waves per SIMD (80 VGPRs / 6 waves otherwise: -9 % time at the headline); with four objects per
 // lane that limit would spill, the default allocation stays.
 #define YAW_COUNT_MERGED_ARGS                                                                                         \
-    MergedView c1, CatView c2, const int32_t *__restrict__ lane_k, const Item *__restrict__ items, int n_bins,        \
+    MergedView c1, CatView c2, const Item *__restrict__ items, int n_bins,                                            \
         int n_edges, const double *__restrict__ t, const float *__restrict__ dthr, const double *__restrict__ rwin_k, \
         int64_t item_base, unsigned long long *__restrict__ out_counts, double *__restrict__ partials,                \
         const unsigned long long *__restrict__ counters
-#define YAW_COUNT_MERGED_PASS c1, c2, lane_k, items, n_bins, n_edges, t, dthr, rwin_k, item_base, out_counts, partials, counters
-template <int R, bool WEIGHTED, bool NF1, int MODE>
+#define YAW_COUNT_MERGED_PASS c1, c2, items, n_bins, n_edges, t, dthr, rwin_k, item_base, out_counts, partials, counters
+template <int R, bool WEIGHTED, bool NF1, bool MERGED>
 __global__ __launch_bounds__(MWG) void k_count_merged(YAW_COUNT_MERGED_ARGS) {
-    count_merged_body<R, WEIGHTED, NF1, MODE>(YAW_COUNT_MERGED_PASS);
+    count_merged_body<R, WEIGHTED, NF1, MERGED>(YAW_COUNT_MERGED_PASS);
 }
-template <int R, bool WEIGHTED, bool NF1, int MODE>
+template <int R, bool WEIGHTED, bool NF1, bool MERGED>
 __global__ __launch_bounds__(MWG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_count_merged_occ8(YAW_COUNT_MERGED_ARGS) {
-    count_merged_body<R, WEIGHTED, NF1, MODE>(YAW_COUNT_MERGED_PASS);
+    count_merged_body<R, WEIGHTED, NF1, MERGED>(YAW_COUNT_MERGED_PASS);
 }
 
-template <int R, bool WEIGHTED, bool NF1, int MODE>
+template <int R, bool WEIGHTED, bool NF1, bool MERGED>
 auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
-    if constexpr (R <= 2) return k_count_merged_occ8<R, WEIGHTED, NF1, MODE>;
-    else return k_count_merged<R, WEIGHTED, NF1, MODE>;
+    if constexpr (R <= 2) return k_count_merged_occ8<R, WEIGHTED, NF1, MERGED>;
+    else return k_count_merged<R, WEIGHTED, NF1, MERGED>;
 }
 
 // Evaluated pairs per job (na * nb of the job's kept items): the cost the host balances over GPUs.
@@ -896,7 +875,6 @@ struct yawhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
-    int binned_strips = 0;   // 1: binned x binned counts use the strip layout too (k_count_merged MODE 2)
     int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
@@ -1231,10 +1209,6 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->seg_strips = value != 0;
         return YAWHIP_OK;
     }
-    if (!strcmp(key, "binned_strips")) {
-        ctx->binned_strips = value != 0;
-        return YAWHIP_OK;
-    }
     if (!strcmp(key, "debug_no_hits")) {
         ctx->debug_no_hits = value != 0;
         return YAWHIP_OK;
@@ -1518,15 +1492,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool strips = lean && c1->strips.x != nullptr && c2->strips.x != nullptr && c1->strip_width == c2->strip_width &&
                         c1->strip_axis == c2->strip_axis &&
                         (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
-    // mode 2 is opt-in: at 30 bins it evaluates ~3x more pairs than the ordinary per-bin items
     // mode 3: binned x binned on the per-segment strip layouts (built at upload for dense catalogues only): ordinary
     // (job, bin) items whose lane tiles and windows come from (patch, bin, strip) runs
     // -- it pays when the lane side is dense: runs of at least a few lane tiles per (patch, bin, strip)
     const bool seg_ok = strips && c1->seg.x != nullptr && c2->seg.x != nullptr && c1->nb == n_bins && c2->nb == n_bins && ctx->seg_strips &&
                         c2->n / std::max<int64_t>(c2->seg.h_vbase[(size_t)c2->seg.n_groups], 1) >= ctx->seg_min_run;
-    const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1
-                     : (ctx->binned_strips && c1->nb > 1 && c2->nb > 1 && n_bins <= BIN_MASK + 1) ? 2 : (seg_ok ? 3 : 0);
-    const bool merged = mode == 1 || mode == 2;   // one item covers all bins, output slot = job
+    const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1 : (seg_ok ? 3 : 0);
+    const bool merged = mode == 1;                // one item covers all bins, output slot = job
     const bool strip_items = mode != 0;           // items come from strip runs (k_build_items_strips)
     const StripLayout &sl1 = mode == 3 ? c1->seg : c1->strips, &sl2 = mode == 3 ? c2->seg : c2->strips;
     int R = ctx->tile_r;
@@ -1630,15 +1602,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     for (int k = 0; k < n_bins; ++k) {
         const double thi = t[(size_t)k * n_edges + n_edges - 1];
         float thr32 = ctx->debug_no_hits ? 2.0f : round_down(1.0 - 0.5 * thi - FILTER_GUARD);
-        if (mode == 2) {
-            // bin id in the low mantissa bits; the value may only move down (keeps the filter conservative)
-            if (!(thr32 >= 1e-30f)) thr32 = std::min(thr32, -1e-30f);
-            uint32_t bits;
-            memcpy(&bits, &thr32, sizeof bits);
-            bits = thr32 > 0.f ? ((bits - (BIN_MASK + 1)) & ~(uint32_t)BIN_MASK) : ((bits + BIN_MASK + 1) & ~(uint32_t)BIN_MASK);
-            bits |= (uint32_t)k;
-            memcpy(&thr32, &bits, sizeof bits);
-        }
         dthr[(size_t)3 * k] = thr32;
         dthr[(size_t)3 * k + 1] = 0.f;  // reserved
         dthr[(size_t)3 * k + 2] = 0.f;
@@ -1753,8 +1716,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                           : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
         const CatView lanes = strip_items ? CatView{sl2.x, sl2.y, sl2.z, sl2.w, sl2.off, 1, key_of(sl2.x, sl2.y, sl2.z, c2->axis), c2->axis}
                                           : view_of(c2);
-        const int32_t *lane_k = mode == 2 ? sl2.k : nullptr;
-        const int kmode = merged ? mode : 0;  // kernel form: per-bin items (0) also serve the per-segment strip layouts
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = 1ll << 30;
             for (int64_t base = 0; base < n_items; base += max_grid) {
@@ -1767,7 +1728,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(MWG), lds_merged, ctx->stream, mv, lanes, lane_k, ctx->d_items.ptr,    \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(MWG), lds_merged, ctx->stream, mv, lanes, ctx->d_items.ptr,            \
                            n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,  \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
@@ -1777,7 +1738,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     } while (0)
 #define YAW_LAUNCH_LEAN_M(WW, NN)                                                                                     \
     do {                                                                                                              \
-        if (kmode == 1) YAW_LAUNCH_LEAN_R(WW, NN, 1); else if (kmode == 2) YAW_LAUNCH_LEAN_R(WW, NN, 2); else YAW_LAUNCH_LEAN_R(WW, NN, 0); \
+        if (merged) YAW_LAUNCH_LEAN_R(WW, NN, true); else YAW_LAUNCH_LEAN_R(WW, NN, false);                           \
     } while (0)
                 const bool nf1 = nf == 1;
                 if (wgt) {
