@@ -59,6 +59,7 @@ constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel 
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
 constexpr int SEG_STRIPS_MIN_RUN = 40;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
+constexpr int64_t SYNC_GRID_MIN_ITEMS = 400000;  // potential items from which the count grid is sized exactly (one host sync)
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
@@ -1668,9 +1669,10 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         // number the builder kept (device counter): no host round trip between the two kernels.
         HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
         n_items = n_pot;
-        if (strip_items) {
+        if (strip_items && n_pot > SYNC_GRID_MIN_ITEMS) {
             // The strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
-            // dispatching workgroups that exit at once (measured, 10M x 10M), more than this round trip costs.
+            // dispatching workgroups that exit at once (measured at 1.6e6 potential items, 10M x 10M), more than
+            // this round trip (~0.05 ms) costs. Small calls (one GPU's share of a sharded job list) skip it.
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             n_items = (int64_t)ctr[0];
         }
