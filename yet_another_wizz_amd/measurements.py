@@ -128,6 +128,22 @@ def best_sort_axis(center_xyz, num_records) -> int:
     return int(np.argmin(np.abs(mean)))
 
 
+_PLAN_CACHE: list = []  # (config, plans, thresholds) of the last few configurations (they are immutable)
+
+
+def _plans_for(config):
+    """Angular plans and threshold table of a configuration; every measurement with the same
+    configuration object (each builds its own PatchLinkage) shares them."""
+    for cfg, plans, thresholds in _PLAN_CACHE:
+        if cfg is config:
+            return plans, thresholds
+    plans = angular_plans(config)
+    thresholds = threshold_table(plans)
+    _PLAN_CACHE.append((config, plans, thresholds))
+    del _PLAN_CACHE[:-4]
+    return plans, thresholds
+
+
 class PatchLinkage:
     """Which patch pairs can contain pairs of objects within the largest scale.
 
@@ -147,8 +163,7 @@ class PatchLinkage:
 
     def _angular_setup(self):
         if self._plans is None:
-            self._plans = angular_plans(self.config)
-            self._thresholds = threshold_table(self._plans)
+            self._plans, self._thresholds = _plans_for(self.config)
         return self._plans, self._thresholds
 
     @classmethod
