@@ -956,7 +956,7 @@ hipError_t launch_count(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    const int64_t max_grid = 1ll << 30;
+    const int64_t max_grid = (1ll << 31) / WG;  // a launch addresses at most 2^32 - 1 work-items per dimension
     for (int64_t base = 0; base < n_items; base += max_grid) {
         const int64_t g = std::min(max_grid, n_items - base);
         hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WG), lds_bytes, ctx->stream, view_of(c1), view_of(c2),
@@ -1719,7 +1719,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         const CatView lanes = strip_items ? CatView{sl2.x, sl2.y, sl2.z, sl2.w, sl2.off, 1, key_of(sl2.x, sl2.y, sl2.z, c2->axis), c2->axis}
                                           : view_of(c2);
         auto launch_lean = [&](bool wgt) -> hipError_t {
-            const int64_t max_grid = 1ll << 30;
+            const int64_t max_grid = (1ll << 31) / MWG;  // at most 2^32 - 1 work-items per launch dimension
             for (int64_t base = 0; base < n_items; base += max_grid) {
                 const unsigned g = (unsigned)std::min(max_grid, n_items - base);
 #define YAW_LAUNCH_LEAN(RR, WW, NN, MM)                                                                               \
