@@ -220,3 +220,42 @@ def test_sort_axis_follows_the_footprint():
     assert best_sort_axis(np.array([[0.99, 0.1, 0.0], [0.98, 0.0, 0.2], [0.97, 0.2, 0.1]]), ones) in (1, 2)   # around +x
     full = np.array([[1.0, 0, 0], [-1.0, 0, 0], [0, 1.0, 0], [0, -1.0, 0], [0, 0, 1.0], [0, 0, -1.0]])
     assert best_sort_axis(full, np.ones(6)) == 2  # no preferred direction: keep z
+
+
+def test_strip_spacing_rule_and_small_helpers():
+    """Pure host helpers around the device path: grid spacing chosen from the thresholds, the radix argsort used
+    for patch / segment keys, and the per-configuration cache of angular plans."""
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import catalog, engine, measurements
+
+    chord = lambda arcmin: (2.0 * np.sin(arcmin * np.pi / 10800 / 2.0)) ** 2
+    assert engine.strip_micro_for(np.array([[chord(1.0), chord(10.0)]])) == 4400     # 1.5 x chord(10')
+    assert engine.strip_micro_for(np.array([[chord(0.1), chord(0.5)]])) == 1000      # lower clamp
+    assert engine.strip_micro_for(np.array([[chord(60.0), chord(3000.0)]])) == 100000  # upper clamp
+    rng = np.random.default_rng(3)
+    for num in (7, 70000):  # uint16 radix path and the general path
+        keys = rng.integers(0, num, 5000)
+        assert np.array_equal(catalog._stable_argsort_small(keys, num), np.argsort(keys, kind="stable"))
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=5)
+    plans, t = measurements._plans_for(config)
+    assert measurements._plans_for(config)[1] is t and t.shape == (5, 2)
+    other = yaw.Configuration.create(rmin=2.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=5)
+    assert measurements._plans_for(other)[1] is not t
+
+
+def test_device_helpers_fall_back_or_fail_as_documented(monkeypatch):
+    """Without a GPU: patch assignment (catalogue preparation) quietly uses scipy, the pair-count entry
+    points raise."""
+    from yet_another_wizz_amd import _lib, catalog, engine
+
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    rng = np.random.default_rng(4)
+    v = rng.normal(size=(1000, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+    c = rng.normal(size=(5, 3)); c /= np.linalg.norm(c, axis=1)[:, None]
+    assert engine.assign_patches(v, c) is None
+    monkeypatch.setattr(catalog, "DEVICE_ASSIGN_MIN", 10)
+    ids = catalog.nearest_center(v, c)
+    assert np.array_equal(ids, ((v[:, None, :] - c[None, :, :]) ** 2).sum(axis=2).argmin(axis=1))
+    with pytest.raises(_lib.YawhipError):
+        engine.get_context()
