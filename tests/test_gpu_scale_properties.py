@@ -71,7 +71,7 @@ def test_strips_cull_but_do_not_change_counts(setup):
         evaluated[micro] = st.evaluated_pairs
         for d in devs:
             d.free()
-    assert engine.strip_micro_for(s["t"]) == 4400  # 1.5 x chord of 10 arcmin
+    assert engine.strip_micro_for(s["t"]) == 3000  # just above the chord of 10 arcmin (2909)
     assert max(evaluated["auto"], evaluated[2000], evaluated[20000]) < 0.6 * evaluated[0]
     assert evaluated["auto"] < evaluated[20000]
 

@@ -229,7 +229,7 @@ def test_strip_spacing_rule_and_small_helpers():
     from yet_another_wizz_amd import catalog, engine, measurements
 
     chord = lambda arcmin: (2.0 * np.sin(arcmin * np.pi / 10800 / 2.0)) ** 2
-    assert engine.strip_micro_for(np.array([[chord(1.0), chord(10.0)]])) == 4400     # 1.5 x chord(10')
+    assert engine.strip_micro_for(np.array([[chord(1.0), chord(10.0)]])) == 3000     # just above chord(10') = 2909
     assert engine.strip_micro_for(np.array([[chord(0.1), chord(0.5)]])) == 1000      # lower clamp
     assert engine.strip_micro_for(np.array([[chord(60.0), chord(3000.0)]])) == 100000  # upper clamp
     rng = np.random.default_rng(3)

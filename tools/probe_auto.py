@@ -23,6 +23,8 @@ if os.environ.get("YAW_SEG"):
     engine.get_context().set_option("seg_strips", int(os.environ["YAW_SEG"]))
 if os.environ.get("YAW_SEG_MIN_RUN"):
     engine.get_context().set_option("seg_strips_min_run", int(os.environ["YAW_SEG_MIN_RUN"]))
+if os.environ.get("YAW_STRIP_MICRO"):
+    engine.forced_strip_micro = int(os.environ["YAW_STRIP_MICRO"])
 if os.environ.get("YAW_TILE_R"):
     engine.get_context().set_option("tile_r", int(os.environ["YAW_TILE_R"]))
 config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=30)

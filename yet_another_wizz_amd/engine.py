@@ -36,10 +36,11 @@ def release() -> None:
 
 def strip_micro_for(thresholds) -> int:
     """Spacing of the strip grid (1e-6 chord units) that suits the widest separation of a threshold
-    table: about 1.5 x the largest chord. Measured on the 10M x 10M headline (chord 0.0029): 3500-5000
-    are within 2 % of each other, 2000 and 10000 are 20-30 % slower."""
+    table: just above the largest chord, so that a run has partners in three strips only and those are
+    as narrow as possible. Measured on the 10M x 10M headline (chord 2909): 2950 -> 2.09 ms per step,
+    3600 -> 2.16, 4400 -> 2.21, 5200 -> 2.28; below the chord five strips take part (2000: 30 % slower)."""
     r = float(np.sqrt(np.max(thresholds)))
-    return int(min(max(round(1.5e6 * r, -2), 1000), 100000))
+    return int(min(max(np.ceil(1.02e6 * r / 50.0) * 50.0, 1000), 100000))
 
 
 def device_catalog(layout, ctx=None, sort_axis: int = 2, strip_micro: int | None = None,
