@@ -1411,6 +1411,7 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(e, "finish");
     free_tmp();
+    if (ctx->sort_ws.cap > ((size_t)1 << 25)) ctx->sort_ws.release();  // ~30 bytes per object: keep only small workspaces
     *out = c;
     return YAWHIP_OK;
 }
