@@ -18,6 +18,19 @@ import types
 REFERENCE_SRC = "/root/reference/src"
 
 
+# module-level (picklable: the reference's process pool pickles the Configuration with its cosmology)
+class FLRW:
+    pass
+
+
+class _Planck15(FLRW):
+    name = "Planck15"
+
+
+class Quantity:
+    pass
+
+
 def load_reference(num_threads: int = 1):
     os.environ.setdefault("YAW_NUM_THREADS", str(num_threads))
     if "yaw" in sys.modules:
@@ -41,15 +54,6 @@ def load_reference(num_threads: int = 1):
     mod("strenum", StrEnum=StrEnum)
     mod("h5py", File=None, Group=object)
     mod("treecorr")
-
-    class FLRW:
-        pass
-
-    class _Planck15(FLRW):
-        name = "Planck15"
-
-    class Quantity:
-        pass
 
     units = mod("astropy.units", Quantity=Quantity, Mpc=1.0)
     cosmo = mod(

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Time the REFERENCE's own CPU path on bench.py's workload (build container only; needs /root/reference).
+
+What is timed is exactly the call the GPU path replaces: ``PatchLinkage.count_pairs(reference, unknown)``
+(/root/reference/src/yaw/correlation/measurements.py:307-367 -> process_patch_pair :88-128 ->
+AngularTree.count, catalog/trees.py:303-362 -> scipy KDTree.count_neighbors) with the KD-trees already
+built (the tree build is reported separately), once with one worker and once with all cores
+(``max_workers``; the reference's multiprocessing pool, utils/parallel.py:251-346).
+Inputs are bench.py's: same seeds, same Fibonacci patch centres, same binning and scales, so the candidate
+pair count and the pair counts themselves are those of the GPU bench line.
+
+    python tools/time_reference.py --n-ref 10e6 --n-unk 10e6 --patches 64 --out profiles/reference_cpu_10Mx10M.json
+
+The JSON it writes is a tracked, small file that bench.py quotes as ``cpu_baseline.reference``.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import platform
+import shutil
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-ref", type=float, default=10e6)
+    ap.add_argument("--n-unk", type=float, default=10e6)
+    ap.add_argument("--patches", type=int, default=64)
+    ap.add_argument("--zbins", type=int, default=30)
+    ap.add_argument("--workers", type=int, nargs="+", default=[8, 1])
+    ap.add_argument("--cache", default="/dev/shm/yaw_ref_timing")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+
+    os.environ["YAW_NUM_THREADS"] = str(max(args.workers))
+    from ref_loader import load_reference
+
+    yaw = load_reference(max(args.workers))
+    import pandas as pd
+    import scipy
+    from yaw.coordinates import AngularCoordinates
+    from yaw.correlation.measurements import PatchLinkage
+
+    import bench  # input recipe only (fibonacci_centers, uniform_sky): no GPU code is touched
+
+    n_ref, n_unk = int(args.n_ref), int(args.n_unk)
+    centers = AngularCoordinates(bench.fibonacci_centers(args.patches))
+    shutil.rmtree(args.cache, ignore_errors=True)
+    os.makedirs(args.cache)
+
+    t0 = time.perf_counter()
+    ra, dec, rng = bench.uniform_sky(101, n_ref)
+    z = rng.uniform(0.1, 1.0, n_ref)
+    ref = yaw.Catalog.from_dataframe(os.path.join(args.cache, "ref"), pd.DataFrame(dict(ra=ra, dec=dec, z=z)), ra_name="ra",
+                                     dec_name="dec", redshift_name="z", patch_centers=centers, degrees=False)
+    ra, dec, rng = bench.uniform_sky(202, n_unk)
+    unk = yaw.Catalog.from_dataframe(os.path.join(args.cache, "unk"), pd.DataFrame(dict(ra=ra, dec=dec)), ra_name="ra",
+                                     dec_name="dec", patch_centers=centers, degrees=False)
+    del ra, dec, z
+    ingest_s = time.perf_counter() - t0
+    print(f"catalogues cached in {ingest_s:.1f} s", flush=True)
+
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
+    t0 = time.perf_counter()
+    ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    unk.build_trees(None)
+    trees_s = time.perf_counter() - t0
+    print(f"trees built in {trees_s:.1f} s ({max(args.workers)} workers)", flush=True)
+
+    links = PatchLinkage.from_catalogs(config, ref, unk)
+    jobs = list(links.iter_patch_id_pairs(auto=False))
+    nrec_ref = np.array([ref[i].meta.num_records for i in range(args.patches)], dtype=np.float64)
+    nrec_unk = np.array([unk[i].meta.num_records for i in range(args.patches)], dtype=np.float64)
+    cand = float(sum(nrec_ref[i] * nrec_unk[j] for i, j in jobs))
+
+    runs = []
+    total = None
+    for w in args.workers:
+        t0 = time.perf_counter()
+        (counts,) = links.count_pairs(ref, unk, max_workers=w)
+        secs = time.perf_counter() - t0
+        found = float(counts.counts.counts.sum())
+        if total is None:
+            total = found
+        assert found == total
+        runs.append(dict(workers=w, seconds=secs, effective_pairs_per_s=cand / secs, found_pairs_per_s=found / secs))
+        print(f"count_pairs, {w} workers: {secs:.2f} s -> {cand / secs:.3e} effective candidate pairs/s", flush=True)
+
+    out = dict(
+        what="reference PatchLinkage.count_pairs(reference, unknown), trees pre-built (measurements.py:307-367)",
+        workload=f"{n_ref} ref x {n_unk} unk uniform full sky, {args.zbins} z-bins, {args.patches} patches, 1-10 arcmin",
+        n_ref=n_ref, n_unk=n_unk, patches=args.patches, z_bins=args.zbins, linked_patch_pairs=len(jobs),
+        candidate_pairs=cand, found_pairs=total, pairs_per_bin=counts.counts.counts.sum(axis=(1, 2)).tolist(),
+        runs=runs, tree_build_s=trees_s, ingest_s=ingest_s,
+        cpu_model=_cpu_model(), cores_available=os.cpu_count(), scipy=scipy.__version__, numpy=np.__version__,
+        python=platform.python_version(), where="build container (not the GPU box: the reference cannot travel)",
+    )
+    print(json.dumps(out))
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(out, f, indent=1)
+    shutil.rmtree(args.cache, ignore_errors=True)
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor()
+
+
+if __name__ == "__main__":
+    main()

@@ -799,6 +799,208 @@ auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
     else return k_count_merged<R, WEIGHTED, NF1, MERGED>;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Band kernel (BAND, the default). Same work items as k_count_merged -- (lane tile of 64*R consecutive objects of a
+// c2 run) x (the window of a c1 run that can hold their partners) -- but the window is not evaluated as a full
+// rectangle. Both sides are sorted along u, so the partners of ONE lane object inside the window are the contiguous
+// index range with |du| <= r_win: a band of ~2 r_win * (objects per unit u) entries, of which about half are real
+// pairs when the strips are about r_win wide (disc / bounding box), against 64*R + band entries per lane object for
+// the rectangle. So:
+//   * the window is staged in LDS once, as float64 SoA columns (x, y, z, bin id, weight), BCAP objects at a time;
+//   * every lane object finds its own band [lo, hi) by two branch-free binary searches on the staged sort-axis column;
+//   * the lane walks its band: per step one staged object per lane (consecutive lanes read consecutive addresses:
+//     conflict-free ds_read_b64), the exact float64 predicate, and the histogram update -- no float32 pre-filter,
+//     no survivor queue, no gathers from global memory.
+// At the headline density a lane object meets ~14 entries per strip instead of ~200; every evaluated entry costs
+// 8 FP64 operations, which is what the parity contract asks for anyway.
+// Work distribution: the grid is sized on the host from the number of POTENTIAL items (no host round trip for the
+// number the builder kept); a workgroup takes the kept items v = blockIdx.x, blockIdx.x + gridDim.x, ... and maps v
+// to the item list so that the workgroups of one XCD (blockIdx.x mod 8, MI355X_MICROARCH.md "Workgroup dispatch")
+// walk one contiguous eighth of the list: consecutive items share c1 runs and lane tiles, which then hit in that
+// XCD's L2 instead of being fetched by all eight.
+//   UNI: all redshift bins share one threshold row (angular scales): edges live in registers.
+// ------------------------------------------------------------------------------------------------
+constexpr int BCAP = 160;  // window objects per LDS stage: 160 * 28 B + tables < 5 KB -> 32 single-wave workgroups per CU
+constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
+
+template <int R, bool WEIGHTED, bool NF1, bool MERGED, bool UNI>
+__global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, const Item *__restrict__ items, int n_bins,
+                                                   int n_edges, const double *__restrict__ t,
+                                                   const double *__restrict__ rwin_k, unsigned flush_mask,
+                                                   unsigned long long *__restrict__ out_counts,
+                                                   double *__restrict__ partials,
+                                                   unsigned long long *__restrict__ counters) {
+    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int nkb = MERGED ? n_bins : 1;  // bins one item can add to
+    const int nf = n_edges - 1;
+    const int nslots = nkb * nf;
+    double *sx = reinterpret_cast<double *>(lds_raw);  // [BCAP] each
+    double *sy = sx + BCAP, *sz = sy + BCAP;
+    double *sw = sz + BCAP;                                                  // weighted only
+    double *thr = sz + (WEIGHTED ? 2 : 1) * BCAP;                            // [nkb][n_edges]
+    HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)nkb * n_edges);    // [nkb][nf]
+    int *sk = reinterpret_cast<int *>(hist + nslots);                        // [BCAP] merged only
+    const int lane = threadIdx.x;
+    const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);
+
+    const unsigned long long n_kept = counters[0];
+    const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
+        const unsigned long long j = v >> 3;
+        if (j >= chunk) break;
+        const unsigned long long ticket = (v & 7) * chunk + j;
+        if (ticket >= n_kept) continue;  // short last eighth
+        const Item it = items[ticket];
+        const int kfix = MERGED ? 0 : it.slot % n_bins;
+        const double rwin = rwin_k[kfix];
+        const int64_t b0 = it.b0, nb_total = it.nb;
+        const int64_t a_end = it.a0 + it.na;
+
+        // all global loads of the item back to back: lane objects, first stage, thresholds
+        double ax[R], ay[R], az[R], aw[R];
+        bool ok[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = it.a0 + (int64_t)r * 64 + lane;
+            ok[r] = i < a_end;
+            const int64_t ic = ok[r] ? i : it.a0;
+            ax[r] = c2.x[ic]; ay[r] = c2.y[ic]; az[r] = c2.z[ic];
+            aw[r] = (WEIGHTED && c2.w) ? c2.w[ic] : 1.0;
+        }
+        constexpr int NPF = (BCAP + 63) / 64;
+        double fx[NPF], fy[NPF], fz[NPF], fw[NPF];
+        int fk[NPF];
+        auto fetch = [&](int64_t first) {  // stage starting at window entry `first` -> registers
+#pragma unroll
+            for (int f = 0; f < NPF; ++f) {
+                const int64_t e = first + f * 64 + lane;
+                const int64_t ic = b0 + (e < nb_total ? e : nb_total - 1);
+                fx[f] = c1.x[ic]; fy[f] = c1.y[ic]; fz[f] = c1.z[ic];
+                fk[f] = MERGED ? c1.k[ic] : 0;
+                fw[f] = (WEIGHTED && c1.w) ? c1.w[ic] : 1.0;
+            }
+        };
+        fetch(0);
+        __syncthreads();  // the previous item of this workgroup has left the LDS
+        for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
+        for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);
+        double t_lo = 0.0, t_hi = 0.0;  // edges of the item's bin (or of every bin) in registers
+        if (!MERGED || UNI) {
+            t_lo = t[(int64_t)kfix * n_edges];
+            t_hi = t[(int64_t)kfix * n_edges + n_edges - 1];
+        }
+        double klo[R], khi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double ua = c2.axis == 0 ? ax[r] : (c2.axis == 1 ? ay[r] : az[r]);
+            klo[r] = ua - rwin;
+            khi[r] = ua + rwin;
+        }
+        unsigned int cnt1 = 0;             // NF1 && !MERGED: the item's only counter lives in a register
+        unsigned long long nev = 0;        // band entries this lane evaluated
+        unsigned stage_no = 0;
+        auto flush = [&]() {  // LDS histogram -> global result (unweighted) / slab (weighted); called at the end of the item
+            if (NF1 && !MERGED && !WEIGHTED) {
+                if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)it.slot * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
+                cnt1 = 0;
+                return;
+            }
+            __syncthreads();
+            for (int idx = lane; idx < nslots; idx += 64) {
+                if (WEIGHTED) {
+                    partials[(int64_t)it.pot * nslots + idx] = reinterpret_cast<double *>(hist)[idx];
+                } else {
+                    const unsigned int c = reinterpret_cast<unsigned int *>(hist)[idx];
+                    if (c) atomicAdd(&out_counts[(int64_t)it.slot * nslots + idx], (unsigned long long)c);
+                    reinterpret_cast<unsigned int *>(hist)[idx] = 0u;
+                }
+            }
+        };
+
+        for (int64_t st0 = 0; st0 < nb_total; st0 += BCAP, ++stage_no) {
+            const int n = (int)(nb_total - st0 < BCAP ? nb_total - st0 : BCAP);
+            if (st0 > 0) {
+                fetch(st0);
+                __syncthreads();  // every lane is done with the previous stage
+            }
+#pragma unroll
+            for (int f = 0; f < NPF; ++f) {
+                const int e = f * 64 + lane;
+                if (e < n) {
+                    sx[e] = fx[f]; sy[e] = fy[f]; sz[e] = fz[f];
+                    if (MERGED) sk[e] = fk[f];
+                    if (WEIGHTED) sw[e] = fw[f];
+                }
+            }
+            __syncthreads();
+            // band of every lane object inside this stage: [lo, hi) = entries with klo <= key <= khi
+            int lo[R], hi[R];
+            const int top = 1 << (31 - __builtin_clz(n));  // largest power of two <= n
+#pragma unroll
+            for (int r = 0; r < R; ++r) lo[r] = hi[r] = 0;
+            for (int step = top; step > 0; step >>= 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pl = lo[r] + step, ph = hi[r] + step;
+                    const double kl = skey[(pl < n ? pl : n) - 1], kh = skey[(ph < n ? ph : n) - 1];
+                    if (pl <= n && kl < klo[r]) lo[r] = pl;    // entries [0, lo) have key <  klo
+                    if (ph <= n && kh <= khi[r]) hi[r] = ph;   // entries [0, hi) have key <= khi
+                }
+            }
+            int len = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!ok[r]) hi[r] = lo[r];
+                len = max(len, hi[r] - lo[r]);
+                nev += (unsigned long long)(hi[r] - lo[r]);
+            }
+            for (int s = 0; __builtin_amdgcn_ballot_w64(s < len) != 0ull; ++s) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int idx = lo[r] + s;
+                    const bool act = idx < hi[r];
+                    const int ic = act ? idx : 0;
+                    const double bx = sx[ic], by = sy[ic], bz = sz[ic];
+                    const int kb = MERGED ? sk[ic] : 0;
+                    const double dx = ax[r] - bx;
+                    const double dy = ay[r] - by;
+                    const double dz = az[r] - bz;
+                    const double xx = dx * dx;
+                    const double yy = dy * dy;
+                    const double zz = dz * dz;
+                    const double sxy = xx + yy;
+                    const double sd = sxy + zz;
+                    const double *tk = thr + kb * n_edges;
+                    const double e_lo = (!MERGED || UNI) ? t_lo : tk[0];
+                    const double e_hi = (!MERGED || UNI) ? t_hi : tk[n_edges - 1];
+                    const bool in = act && sd > e_lo && sd <= e_hi;
+                    if (NF1 && !MERGED && !WEIGHTED) {
+                        cnt1 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(in));
+                    } else if (in) {
+                        int hslot = kb * nf;
+                        if (!NF1) {
+                            int c = 0;
+                            for (int e = 0; e < n_edges; ++e) c += (sd > tk[e]) ? 1 : 0;
+                            hslot += c - 1;  // t[c-1] < s <= t[c], c >= 1 because s > t[0]
+                        }
+                        // wave-private LDS histogram: integer adds are exact; float64 adds of ONE instruction that
+                        // hit the same slot are serialised by the LDS in a fixed lane order -> reproducible sums
+                        if (WEIGHTED) atomicAdd(reinterpret_cast<double *>(hist) + hslot, aw[r] * sw[ic]);
+                        else atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
+                    }
+                }
+            }
+            // 64*R lane objects x BCAP entries per stage: a uint32 counter cannot wrap within flush_mask + 1 stages
+            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush();
+        }
+        flush();
+        // evaluated band entries of the item -> one of EVAL_SLOTS counters (statistics)
+        for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
+        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], nev);
+    }
+}
+
 // Evaluated pairs per job (na * nb of the job's kept items): the cost the host balances over GPUs.
 __global__ void k_item_work(const Item *__restrict__ items, const unsigned long long *__restrict__ counters,
                             int slots_per_job, unsigned long long *__restrict__ job_work) {
