@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--n-unk", type=float, default=10e6)
     ap.add_argument("--patches", type=int, default=64)
     ap.add_argument("--zbins", type=int, default=30)
-    ap.add_argument("--kernel", default="auto", choices=["auto", "exact", "filter", "sweep"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "exact", "filter", "sweep", "band"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--tile-r", type=int, default=0, help="objects per lane (0 = library default)")
     ap.add_argument("--debug-no-hits", action="store_true", help="diagnostics: time the pre-filter only (wrong counts)")
@@ -226,7 +226,7 @@ def main():
         #           metric asks. The FP32 pre-filter rate and the brute-force-equivalent rate are reported beside it.
         count_ms = stats.count_ms if stats.count_ms > 0 else stats.kernel_ms
         k_s = max(count_ms, 1e-9) / 1e3
-        kernel_name = {1: "exact", 2: "filter", 3: "sweep"}.get(stats.kernel_used, str(stats.kernel_used))
+        kernel_name = {1: "exact", 2: "filter", 3: "sweep", 4: "band"}.get(stats.kernel_used, str(stats.kernel_used))
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YAWHIP_ABI_VERSION 2
+#define YAWHIP_ABI_VERSION 3
 
 typedef enum yawhip_status {
     YAWHIP_OK = 0,
@@ -42,7 +42,9 @@ typedef enum yawhip_kernel {
     YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path */
     YAWHIP_KERNEL_EXACT = 1,  /* plain FP64 brute force over every candidate pair */
     YAWHIP_KERNEL_FILTER = 2, /* FP32 guard-banded pre-filter, FP64 re-evaluation of survivors */
-    YAWHIP_KERNEL_SWEEP = 3   /* FILTER + sorted-axis sweep that skips far-away tile pairs */
+    YAWHIP_KERNEL_SWEEP = 3,  /* FILTER + sorted-axis sweep that skips far-away tile pairs */
+    YAWHIP_KERNEL_BAND = 4    /* sorted-axis windows as SWEEP, then per-object bands inside the window evaluated
+                                 directly in FP64 (no pre-filter); AUTO picks this one (ABI >= 3) */
 } yawhip_kernel;
 
 typedef struct yawhip_ctx yawhip_ctx;
@@ -81,7 +83,12 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx);
  *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
  *   "seg_strips"        binned x binned counts use the per-(patch, bin) strip layouts of dense catalogues (default 1)
  *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 40)
- *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts) */
+ *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts)
+ *   "auto_orient"       1 (default): every job runs on the strip layouts of the orientation (sort axis u, strips along v,
+ *                       dropped axis w) that suits its two patches -- w pointing at them; layouts of further
+ *                       orientations are built on first use. 0: the sort axis the catalogues were uploaded with
+ *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every
+ *                       2^value stages (default 17: 128 lane objects x 160 entries x 2^17 < 2^32; tests lower it) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 
 /*

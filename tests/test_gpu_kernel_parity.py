@@ -32,7 +32,7 @@ def _single(xyz, w):
                 off=np.array([0, len(xyz)], dtype=np.int64))
 
 
-KERNELS = ["exact", "filter", "sweep"]
+KERNELS = ["exact", "filter", "sweep", "band"]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -245,7 +245,7 @@ def test_merged_path_many_edges_and_bins(ctx, weights):
     assert t.shape == (B, 58)
     d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
     exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
-    for kernel in ("sweep", "exact"):
+    for kernel in ("band", "sweep", "exact"):
         counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
         assert np.array_equal(counts, exp_c), kernel
         if weights == "uu":
@@ -270,7 +270,7 @@ def test_many_survivors_per_object(ctx):
     lim = oracle.parse_ang_limits([0.2 * np.pi / 10800], [3.0 * np.pi / 10800])
     t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (3, 1))
     exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
-    for kernel in ("sweep", "filter"):
+    for kernel in ("band", "sweep", "filter"):
         counts, _, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel=kernel)
         assert np.array_equal(counts, exp), kernel
     assert exp.sum() > 0.5 * n1 * n2
@@ -299,9 +299,19 @@ def test_sort_axis_variants(ctx):
     exp, _ = oracle.count_jobs(c1, c2, jobs, t)
     evaluated = {}
     ctx.set_option("strip_width_micro", 0)  # culling along the sort axis alone
+    ctx.set_option("auto_orient", 0)        # ... the one the catalogues were uploaded with
     try:
         _sort_axis_checks(ctx, c1, c2, jobs, t, exp, evaluated, P, B)
+        # left to itself the library sorts along an axis in the plane of the cap, whatever the upload asked for
+        ctx.set_option("auto_orient", 1)
+        d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=2)
+        d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=2)
+        for kernel in ("band", "sweep"):
+            counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel)
+            assert np.array_equal(counts, exp)
+        assert st.evaluated_pairs <= 1.05 * min(evaluated[0], evaluated[1])
     finally:
+        ctx.set_option("auto_orient", 1)
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
 
 
@@ -311,18 +321,20 @@ def _sort_axis_checks(ctx, c1, c2, jobs, t, exp, evaluated, P, B):
     for axis in (0, 1, 2):
         d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=axis)
         d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=axis)
-        counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="sweep")
-        assert np.array_equal(counts, exp), axis
-        assert st.kernel_used == _lib.KERNEL_SWEEP
-        evaluated[axis] = st.evaluated_pairs
-        counts, _, _ = _lib.count_pairs(ctx, d1, d1, jobs, t, kernel="sweep")  # self count, non-merged path
         exp_self, _ = oracle.count_jobs(c1, c1, jobs, t)
-        assert np.array_equal(counts, exp_self), axis
+        for kernel, kid in (("band", _lib.KERNEL_BAND), ("sweep", _lib.KERNEL_SWEEP)):
+            counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel)
+            assert np.array_equal(counts, exp), (axis, kernel)
+            assert st.kernel_used == kid
+            evaluated[axis] = st.evaluated_pairs
+            counts, _, _ = _lib.count_pairs(ctx, d1, d1, jobs, t, kernel=kernel)  # self count, non-merged path
+            assert np.array_equal(counts, exp_self), (axis, kernel)
     assert evaluated[2] > 2 * min(evaluated[0], evaluated[1])  # z culls worst on a polar cap
     dz = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=2)
     dx = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=0)
-    counts, _, st = _lib.count_pairs(ctx, dz, dx, jobs, t, kernel="sweep")
-    assert np.array_equal(counts, exp) and st.kernel_used == _lib.KERNEL_FILTER and st.evaluated_pairs == st.candidate_pairs
+    for kernel in ("sweep", "band"):
+        counts, _, st = _lib.count_pairs(ctx, dz, dx, jobs, t, kernel=kernel)
+        assert np.array_equal(counts, exp) and st.kernel_used == _lib.KERNEL_FILTER and st.evaluated_pairs == st.candidate_pairs
     with pytest.raises(_lib.YawhipError, match="sort_axis"):
         _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"], sort_axis=3)
 
@@ -378,21 +390,24 @@ def test_strip_widths(ctx, weights):
             d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
             for tile_r in (0, 1, 4):
                 ctx.set_option("tile_r", tile_r)
-                counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="sweep", want_counts=True, want_sums=True)
-                assert st.kernel_used == _lib.KERNEL_SWEEP
-                assert np.array_equal(counts, exp_c), (micro, tile_r)
-                if weights == "ww":
-                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+                for kernel, kid in (("band", _lib.KERNEL_BAND), ("sweep", _lib.KERNEL_SWEEP)):
+                    counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+                    assert st.kernel_used == kid
+                    assert np.array_equal(counts, exp_c), (micro, tile_r, kernel)
+                    if weights == "ww":
+                        np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
             evaluated[micro] = st.evaluated_pairs
             # the sub-slot tables of a call are reused by the next one with the same job list
             for sel in (slice(None), slice(0, 7), slice(0, 7), slice(3, None), slice(None)):
-                counts, _, _ = _lib.count_pairs(ctx, d1, d2, jobs[sel], t, kernel="sweep", want_counts=True)
-                assert np.array_equal(counts, exp_c[sel]), (micro, sel)
+                for kernel in ("band", "sweep"):
+                    counts, _, _ = _lib.count_pairs(ctx, d1, d2, jobs[sel], t, kernel=kernel, want_counts=True)
+                    assert np.array_equal(counts, exp_c[sel]), (micro, sel, kernel)
             if micro == 20000:  # catalogue with another grid: ordinary (job, bin) items
                 ctx.set_option("strip_width_micro", 5000)
                 d2b = _upload(ctx, c2)
-                counts, _, _ = _lib.count_pairs(ctx, d1, d2b, jobs, t, kernel="sweep", want_counts=True)
-                assert np.array_equal(counts, exp_c)
+                for kernel in ("band", "sweep"):
+                    counts, _, _ = _lib.count_pairs(ctx, d1, d2b, jobs, t, kernel=kernel, want_counts=True)
+                    assert np.array_equal(counts, exp_c)
         with pytest.raises(_lib.YawhipError, match="strip_width_micro"):
             ctx.set_option("strip_width_micro", 10)
     finally:
@@ -453,7 +468,7 @@ def test_randomised_configurations(ctx, seed):
         d1, d2 = up(c1), up(c2)
         for a, b, da, db in ((c1, c2, d1, d2), (c1, c1, d1, d1)):
             exp_c, exp_s = oracle.count_jobs(a, b, jobs, t)
-            for kernel in ("sweep", "exact"):
+            for kernel in ("band", "sweep", "exact"):
                 counts, sums, _ = _lib.count_pairs(ctx, da, db, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
                 assert np.array_equal(counts, exp_c), (seed, kernel)
                 if a["w"] is None and b["w"] is None:
@@ -498,10 +513,11 @@ def test_segment_strip_layout_path(ctx, weights):
                     ctx.set_option("seg_strips", seg)
                     for tile_r in (0, 1, 4):
                         ctx.set_option("tile_r", tile_r)
-                        counts, sums, st = _lib.count_pairs(ctx, da, db, jobs, t, kernel="sweep", want_counts=True, want_sums=True)
-                        assert np.array_equal(counts, exp_c), (micro, seg, tile_r)
-                        if weights == "ww":
-                            np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+                        for kernel in ("band", "sweep"):
+                            counts, sums, st = _lib.count_pairs(ctx, da, db, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+                            assert np.array_equal(counts, exp_c), (micro, seg, tile_r, kernel)
+                            if weights == "ww":
+                                np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
                         evaluated[(micro, a is c1, seg, tile_r)] = st.evaluated_pairs
                     work = _lib.job_work(ctx, da, db, jobs, t, kernel="sweep")
                     # (a weighted call that also returns counts runs the kernel twice)

@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--n-unk", type=float, default=10e6)
     ap.add_argument("--patches", type=int, default=64)
     ap.add_argument("--zbins", type=int, default=30)
+    ap.add_argument("--scales", type=int, default=1, choices=[1, 3], help="3: the log-spaced scales of BASELINE config #5")
+    ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5)")
+    ap.add_argument("--auto-randoms", type=float, default=0.0,
+                    help="> 0: BASELINE config #4 -- autocorrelation counts DD, DR, RR of --n-ref data objects and "
+                         "this many randoms (both binned); --n-unk is ignored")
     ap.add_argument("--workers", type=int, nargs="+", default=[8, 1])
     ap.add_argument("--cache", default="/dev/shm/yaw_ref_timing")
     ap.add_argument("--out", default=None)
@@ -58,49 +63,70 @@ def main():
     shutil.rmtree(args.cache, ignore_errors=True)
     os.makedirs(args.cache)
 
+    auto = args.auto_randoms > 0
+    n_rand = int(args.auto_randoms)
+
+    def cached(name, seed, n, with_z):
+        ra, dec, rng = bench.uniform_sky(seed, n)
+        cols = dict(ra=ra, dec=dec)
+        if with_z:
+            cols["z"] = rng.uniform(0.1, 1.0, n)
+        if args.weights:
+            cols["w"] = rng.uniform(0.5, 1.5, n)
+        return yaw.Catalog.from_dataframe(os.path.join(args.cache, name), pd.DataFrame(cols), ra_name="ra", dec_name="dec",
+                                          redshift_name="z" if with_z else None, weight_name="w" if args.weights else None,
+                                          patch_centers=centers, degrees=False)
+
     t0 = time.perf_counter()
-    ra, dec, rng = bench.uniform_sky(101, n_ref)
-    z = rng.uniform(0.1, 1.0, n_ref)
-    ref = yaw.Catalog.from_dataframe(os.path.join(args.cache, "ref"), pd.DataFrame(dict(ra=ra, dec=dec, z=z)), ra_name="ra",
-                                     dec_name="dec", redshift_name="z", patch_centers=centers, degrees=False)
-    ra, dec, rng = bench.uniform_sky(202, n_unk)
-    unk = yaw.Catalog.from_dataframe(os.path.join(args.cache, "unk"), pd.DataFrame(dict(ra=ra, dec=dec)), ra_name="ra",
-                                     dec_name="dec", patch_centers=centers, degrees=False)
-    del ra, dec, z
+    ref = cached("ref", 101, n_ref, True)                                             # seeds: SURVEY.md 8(d)
+    unk = cached("rand", 303, n_rand, True) if auto else cached("unk", 202, n_unk, False)
     ingest_s = time.perf_counter() - t0
     print(f"catalogues cached in {ingest_s:.1f} s", flush=True)
 
-    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
+    rmin, rmax = ([0.5, 1.58, 5.0], [1.58, 5.0, 15.8]) if args.scales == 3 else (1.0, 10.0)
+    config = yaw.Configuration.create(rmin=rmin, rmax=rmax, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins)
     t0 = time.perf_counter()
     ref.build_trees(config.binning.edges, closed=config.binning.closed)
-    unk.build_trees(None)
+    unk.build_trees(config.binning.edges if auto else None, closed=config.binning.closed)
     trees_s = time.perf_counter() - t0
     print(f"trees built in {trees_s:.1f} s ({max(args.workers)} workers)", flush=True)
 
     links = PatchLinkage.from_catalogs(config, ref, unk)
+    passes = [("DD", (ref,)), ("DR", (ref, unk)), ("RR", (unk,))] if auto else [("DD", (ref, unk))]
     jobs = list(links.iter_patch_id_pairs(auto=False))
     nrec_ref = np.array([ref[i].meta.num_records for i in range(args.patches)], dtype=np.float64)
     nrec_unk = np.array([unk[i].meta.num_records for i in range(args.patches)], dtype=np.float64)
-    cand = float(sum(nrec_ref[i] * nrec_unk[j] for i, j in jobs))
+    cand = float(sum(nrec_ref[i] * nrec_unk[j] for i, j in jobs))  # patch-level candidates of the cross count
 
     runs = []
-    total = None
+    totals = {}
     for w in args.workers:
-        t0 = time.perf_counter()
-        (counts,) = links.count_pairs(ref, unk, max_workers=w)
-        secs = time.perf_counter() - t0
-        found = float(counts.counts.counts.sum())
-        if total is None:
-            total = found
-        assert found == total
-        runs.append(dict(workers=w, seconds=secs, effective_pairs_per_s=cand / secs, found_pairs_per_s=found / secs))
-        print(f"count_pairs, {w} workers: {secs:.2f} s -> {cand / secs:.3e} effective candidate pairs/s", flush=True)
+        for name, cats in passes:
+            t0 = time.perf_counter()
+            res = links.count_pairs(*cats, max_workers=w)
+            secs = time.perf_counter() - t0
+            per_scale_bin = np.array([r.counts.counts.sum(axis=(1, 2)) for r in res])  # [S, B]
+            found = float(per_scale_bin.sum())
+            if name not in totals:
+                totals[name] = per_scale_bin
+            assert np.allclose(per_scale_bin, totals[name], rtol=1e-12, atol=0)
+            run = dict(count=name, workers=w, seconds=secs, found_pairs_per_s=found / secs)
+            if not auto:
+                run["effective_pairs_per_s"] = cand / secs
+            runs.append(run)
+            print(f"{name} count_pairs, {w} workers: {secs:.2f} s, {found:.6e} pairs found", flush=True)
+    total = float(totals["DD"].sum())
+    counts = None
 
     out = dict(
         what="reference PatchLinkage.count_pairs(reference, unknown), trees pre-built (measurements.py:307-367)",
-        workload=f"{n_ref} ref x {n_unk} unk uniform full sky, {args.zbins} z-bins, {args.patches} patches, 1-10 arcmin",
-        n_ref=n_ref, n_unk=n_unk, patches=args.patches, z_bins=args.zbins, linked_patch_pairs=len(jobs),
-        candidate_pairs=cand, found_pairs=total, pairs_per_bin=counts.counts.counts.sum(axis=(1, 2)).tolist(),
+        workload=(f"{n_ref} data + {n_rand} randoms autocorrelation (DD, DR, RR)" if auto else f"{n_ref} ref x {n_unk} unk")
+                 + f", uniform full sky, {args.zbins} z-bins, {args.patches} patches, "
+                 + ("1-10 arcmin" if args.scales == 1 else "3 log scales 0.5-15.8 arcmin") + (", weighted" if args.weights else ""),
+        n_ref=n_ref, n_unk=n_rand if auto else n_unk, patches=args.patches, z_bins=args.zbins, scales=args.scales,
+        weighted=bool(args.weights), auto=auto, linked_patch_pairs=len(jobs),
+        candidate_pairs=cand, found_pairs=total, pairs_per_bin=totals["DD"].sum(axis=0).tolist(),
+        pairs_per_scale_bin={k: v.tolist() for k, v in totals.items()},
         runs=runs, tree_build_s=trees_s, ingest_s=ingest_s,
         cpu_model=_cpu_model(), cores_available=os.cpu_count(), scipy=scipy.__version__, numpy=np.__version__,
         python=platform.python_version(), where="build container (not the GPU box: the reference cannot travel)",

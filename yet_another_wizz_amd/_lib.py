@@ -15,8 +15,9 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libyawhip.so")
 
 DEFAULT_STRIP_MICRO = 5000  # the library's default strip grid spacing, in 1e-6 chord units
-KERNEL_AUTO, KERNEL_EXACT, KERNEL_FILTER, KERNEL_SWEEP = 0, 1, 2, 3
-KERNEL_IDS = {"auto": KERNEL_AUTO, "exact": KERNEL_EXACT, "filter": KERNEL_FILTER, "sweep": KERNEL_SWEEP}
+KERNEL_AUTO, KERNEL_EXACT, KERNEL_FILTER, KERNEL_SWEEP, KERNEL_BAND = 0, 1, 2, 3, 4
+KERNEL_IDS = {"auto": KERNEL_AUTO, "exact": KERNEL_EXACT, "filter": KERNEL_FILTER, "sweep": KERNEL_SWEEP,
+              "band": KERNEL_BAND}
 
 # every symbol include/yawhip.h declares (tests check the export list against this)
 ABI_SYMBOLS = (

@@ -110,9 +110,28 @@ struct alignas(16) Item {  // one unit of work for a workgroup
     int64_t b0;    // first streamed object (c1 side)
     int32_t na;    // lane objects (<= 256*R, <= 64*R on the SWEEP path)
     int32_t nb;    // streamed objects
-    int32_t slot;  // output slot: job * n_bins + bin, or the job itself on the strip path
+    int32_t slot;  // output slot: job * n_bins + bin, or the job itself on the strip path (bits 0..29);
+                   // bits 30..31: orientation = which of the catalogues' three strip layouts a0 / b0 index
     int32_t pot;   // index among all potential items (slab index of weighted partial sums)
 };
+constexpr int SLOT_MASK = 0x3fffffff;
+__host__ __device__ inline int item_slot(const Item &it) { return it.slot & SLOT_MASK; }
+__host__ __device__ inline int item_orient(const Item &it) { return (int)((unsigned)it.slot >> 30); }
+
+// One layout of one catalogue as the kernels see it. The count kernels and the strip builder receive a table of six:
+// [o] = layout of c1 for orientation o, [3 + o] = layout of c2 (plain layouts: entry 0 / 3 only).
+// Orientation o = the sort axis u of the layout (0 = x, 1 = y, 2 = z); strips are cut along v = (o + 2) % 3 and the
+// third axis w = (o + 1) % 3 is the one the projection drops: a job uses the orientation whose w points towards its
+// two patches, where the (u, v) projection of the sphere is least compressed.
+struct DevTab {
+    const double *x, *y, *z, *w;          // columns; w may be null
+    const int32_t *k;                     // bin id per object (merged cross-correlation layouts), else null
+    const int64_t *off;                   // run offsets [V+1] (strip layouts) or segment offsets
+    const int64_t *vbase, *slo, *tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
+    int32_t axis;                         // sort axis inside a run / segment
+    int32_t pad_;
+};
+__device__ __forceinline__ const double *tab_key(const DevTab &t) { return t.axis == 0 ? t.x : (t.axis == 1 ? t.y : t.z); }
 
 // ------------------------------------------------------------------------------------------------
 // Item builder: one thread per potential item (slot, lane tile).
@@ -217,15 +236,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
 // job (prefix over jobs), its tile (prefix of tiles over the runs of c2) and the strip of c1 on the common
 // grid; window search and compaction as in k_build_items<true>.
 // ------------------------------------------------------------------------------------------------
-struct StripView {
-    const double *key;       // sort-axis column of the strip layout
-    const int64_t *off;      // [V+1] run offsets
-    const int64_t *vbase;    // [P+1] first run of a patch
-    const int64_t *slo;      // [P]   grid index of a patch's first run
-    const int64_t *tiles;    // [V+1] prefix of lane tiles over the runs (for the tile size of this call)
-};
-
-__global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, StripView c2, const int32_t *__restrict__ jobs,
+__global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *__restrict__ tabs, const int32_t *__restrict__ jobs,
                                                             const int32_t *__restrict__ job_runs,
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
                                                             int tile, double rwin, int64_t n_pot,
@@ -242,12 +253,15 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, S
             if (prefix[mid] <= pot) lo = mid; else hi = mid;
         }
         const int job = lo, p = jobs[2 * job], q = jobs[2 * job + 1];
+        const int o = job_runs[3 * job + 2];  // orientation of the job: which pair of layouts it runs on
+        const DevTab &c1 = tabs[o], &c2 = tabs[3 + o];
+        const double *key1 = tab_key(c1), *key2 = tab_key(c2);
         // potential items of a job, in this order: run of patch q, neighbour offset d, lane tile of the run.
-        // Consecutive workgroups then stream adjacent windows of one c1 run and the three visits of a lane
+        // Consecutive items then stream adjacent windows of one c1 run and the three visits of a lane
         // tile stay close in time (both sides hit in L2).
         const int nd = 2 * reach + 1;
         // runs of patch q whose grid index is within reach of some strip of patch p (host: job_runs)
-        const int64_t r_lo = c2.vbase[q] + job_runs[2 * job], r_hi = r_lo + job_runs[2 * job + 1];
+        const int64_t r_lo = c2.vbase[q] + job_runs[3 * job], r_hi = r_lo + job_runs[3 * job + 1];
         const int64_t t_lo = c2.tiles[r_lo];
         const int64_t local = pot - prefix[job];
         int64_t l = r_lo, h = r_hi;  // run = largest r in [r_lo, r_hi) with nd * tiles-before-r <= local (skips empty runs)
@@ -268,23 +282,24 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(StripView c1, S
             const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
             const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
             if (b1 > b0) {
-                const double wlo = c2.key[a0] - rwin, whi = c2.key[a1 - 1] + rwin;
+                const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
                 l = b0; h = b1;  // first index with key >= wlo
                 while (l < h) {
                     const int64_t m = (l + h) >> 1;
-                    if (c1.key[m] < wlo) l = m + 1; else h = m;
+                    if (key1[m] < wlo) l = m + 1; else h = m;
                 }
                 const int64_t first = l;
                 h = b1;  // first index with key > whi
                 while (l < h) {
                     const int64_t m = (l + h) >> 1;
-                    if (c1.key[m] <= whi) l = m + 1; else h = m;
+                    if (key1[m] <= whi) l = m + 1; else h = m;
                 }
                 b0 = first;
                 b1 = l;
             }
             keep = b1 > b0;
-            it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = job; it.pot = (int32_t)pot;
+            it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0);
+            it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
             work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
         }
     }
@@ -508,7 +523,7 @@ struct MergedView {
 //                 side is dense enough, else on the plain (patch, bin, u) layout -- and everything without a common
 //                 strip grid.
 template <int R, bool WEIGHTED, bool NF1, bool MERGED>
-__device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, const Item *__restrict__ items,
+__device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tabs, const Item *__restrict__ items,
                                                      int n_bins, int n_edges, const double *__restrict__ t,
                                                      const float *__restrict__ dthr, const double *__restrict__ rwin_k,
                                                      int64_t item_base, unsigned long long *__restrict__ out_counts,
@@ -529,7 +544,11 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
     const unsigned long long ticket = item_base + blockIdx.x;
     if (ticket >= counters[0]) return;  // never taken when the host sized the grid from the builder's count
     const Item it = items[ticket];
-    const int kfix = MERGED ? 0 : it.slot % n_bins;  // the item's bin (ordinary items)
+    const int o = item_orient(it), islot = item_slot(it);
+    const DevTab T1 = tabs[o], T2 = tabs[3 + o];
+    const MergedView c1{T1.x, T1.y, T1.z, T1.w, T1.k};
+    const CatView c2{T2.x, T2.y, T2.z, T2.w, T2.off, 1, tab_key(T2), T2.axis};
+    const int kfix = MERGED ? 0 : islot % n_bins;  // the item's bin (ordinary items)
     const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
     const int nslots = nkb * nf;
     const double rwin = rwin_k[kfix];
@@ -770,7 +789,7 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
             partials[(int64_t)it.pot * nslots + idx] = v;
         } else {
             const unsigned int v = reinterpret_cast<unsigned int *>(hist)[idx];
-            if (v) atomicAdd(&out_counts[(int64_t)it.slot * nslots + idx], (unsigned long long)v);
+            if (v) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)v);
         }
     }
 }
@@ -779,11 +798,11 @@ __device__ __forceinline__ void count_merged_body(MergedView c1, CatView c2, con
 // told to keep 8 waves per SIMD (80 VGPRs / 6 waves otherwise: -9 % time at the headline); with four objects per
 // lane that limit would spill, the default allocation stays.
 #define YAW_COUNT_MERGED_ARGS                                                                                         \
-    MergedView c1, CatView c2, const Item *__restrict__ items, int n_bins,                                            \
+    const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,                                      \
         int n_edges, const double *__restrict__ t, const float *__restrict__ dthr, const double *__restrict__ rwin_k, \
         int64_t item_base, unsigned long long *__restrict__ out_counts, double *__restrict__ partials,                \
         const unsigned long long *__restrict__ counters
-#define YAW_COUNT_MERGED_PASS c1, c2, items, n_bins, n_edges, t, dthr, rwin_k, item_base, out_counts, partials, counters
+#define YAW_COUNT_MERGED_PASS tabs, items, n_bins, n_edges, t, dthr, rwin_k, item_base, out_counts, partials, counters
 template <int R, bool WEIGHTED, bool NF1, bool MERGED>
 __global__ __launch_bounds__(MWG) void k_count_merged(YAW_COUNT_MERGED_ARGS) {
     count_merged_body<R, WEIGHTED, NF1, MERGED>(YAW_COUNT_MERGED_PASS);
@@ -822,9 +841,10 @@ auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
 // ------------------------------------------------------------------------------------------------
 constexpr int BCAP = 160;  // window objects per LDS stage: 160 * 28 B + tables < 5 KB -> 32 single-wave workgroups per CU
 constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
+constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries
 
 template <int R, bool WEIGHTED, bool NF1, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask,
                                                    unsigned long long *__restrict__ out_counts,
@@ -842,7 +862,6 @@ __global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, co
     HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)nkb * n_edges);    // [nkb][nf]
     int *sk = reinterpret_cast<int *>(hist + nslots);                        // [BCAP] merged only
     const int lane = threadIdx.x;
-    const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);
 
     const unsigned long long n_kept = counters[0];
     const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
@@ -852,7 +871,10 @@ __global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, co
         const unsigned long long ticket = (v & 7) * chunk + j;
         if (ticket >= n_kept) continue;  // short last eighth
         const Item it = items[ticket];
-        const int kfix = MERGED ? 0 : it.slot % n_bins;
+        const int o = item_orient(it), islot = item_slot(it);
+        const DevTab c1 = tabs[o], c2 = tabs[3 + o];  // wave-uniform: scalar loads
+        const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);
+        const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
         const int64_t b0 = it.b0, nb_total = it.nb;
         const int64_t a_end = it.a0 + it.na;
@@ -902,7 +924,7 @@ __global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, co
         unsigned stage_no = 0;
         auto flush = [&]() {  // LDS histogram -> global result (unweighted) / slab (weighted); called at the end of the item
             if (NF1 && !MERGED && !WEIGHTED) {
-                if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)it.slot * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
+                if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)islot * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
                 cnt1 = 0;
                 return;
             }
@@ -912,7 +934,7 @@ __global__ __launch_bounds__(64) void k_count_band(MergedView c1, CatView c2, co
                     partials[(int64_t)it.pot * nslots + idx] = reinterpret_cast<double *>(hist)[idx];
                 } else {
                     const unsigned int c = reinterpret_cast<unsigned int *>(hist)[idx];
-                    if (c) atomicAdd(&out_counts[(int64_t)it.slot * nslots + idx], (unsigned long long)c);
+                    if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
                     reinterpret_cast<unsigned int *>(hist)[idx] = 0u;
                 }
             }
@@ -1007,7 +1029,7 @@ __global__ void k_item_work(const Item *__restrict__ items, const unsigned long 
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= counters[0]) return;
     const Item it = items[i];
-    atomicAdd(&job_work[it.slot / slots_per_job], (unsigned long long)it.na * (unsigned long long)it.nb);
+    atomicAdd(&job_work[item_slot(it) / slots_per_job], (unsigned long long)it.na * (unsigned long long)it.nb);
 }
 
 // Weighted sums: every kept item left a slab of `slab` float64 values at partials[pot]. They are added per output
@@ -1081,6 +1103,8 @@ struct yawhip_ctx {
     int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
+    int auto_orient = 1;     // every job runs on the strip layouts of the orientation that suits its patches (0: the catalogues' sort axis)
+    int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
@@ -1099,11 +1123,13 @@ struct yawhip_ctx {
     DevBuf<int64_t> d_cprefix;
     DevBuf<unsigned char> d_kept;   // weighted runs: 1 for potential items the builder kept
     DevBuf<unsigned long long> d_jobwork;
+    DevBuf<DevTab> d_tabs;
     yawsort::Workspace sort_ws;  // upload-side sorts
     int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
 
 struct StripLayout {
+    bool built = false;
     double *x = nullptr, *y = nullptr, *z = nullptr, *w = nullptr;
     int32_t *k = nullptr;             // bin id per object (patch-level layout of a binned catalogue)
     int64_t *off = nullptr;           // [V+1] offsets of the runs
@@ -1113,12 +1139,14 @@ struct StripLayout {
     std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
     int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
     int64_t n_groups = 0;
+    int64_t device_bytes = 0;
     void release() {
         for (void *q : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)off, (void *)d_vbase, (void *)d_slo,
                         (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2]})
             if (q) (void)hipFree(q);
         x = y = z = w = nullptr; k = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
+        built = false;
     }
 };
 
@@ -1137,9 +1165,12 @@ struct yawhip_catalog {
     // differ by at most sqrt(t_max) / spacing + 1.
     //   strips: group = patch, all redshift bins together, bin id per object (cross-correlation counts);
     //   seg:    group = (patch, bin) segment (binned x binned counts of dense catalogues; binned catalogues only).
-    StripLayout strips, seg;
+    // One layout per orientation o = sort axis u (strips along (o + 2) % 3), built when a job first needs it (the one of
+    // the catalogue's own sort axis at upload): see DevTab.
+    StripLayout strips[3], seg[3];
+    bool has_strips = false;          // strip layouts can be built (unit vectors, n > 0)
     double strip_width = 0.0;         // grid spacing (chord units); 0 = one run per patch
-    int strip_axis = 0;
+    std::vector<double> h_box;        // [P][6] bounding box of every patch: min x, y, z, max x, y, z (empty patch: +4 / -4)
 };
 
 namespace {
@@ -1305,10 +1336,174 @@ __global__ void k_run_offsets(const uint32_t *__restrict__ run_sorted, int64_t n
     moff[r] = lo;
 }
 
+// monotone map double -> uint64 (atomicMin / atomicMax on the images order like the doubles)
+__host__ __device__ inline unsigned long long sortable_of(double d) {
+    unsigned long long b;
+    memcpy(&b, &d, sizeof b);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+inline double double_of(unsigned long long s) {
+    const unsigned long long b = (s >> 63) ? (s & 0x7fffffffffffffffull) : ~s;
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d;
+}
+
+// Bounding box of every patch ([P][6]: min x, y, z, max x, y, z as sortable images) and, in box[6 P], the number of
+// waves that saw an object off the unit sphere. One atomic set per wave inside a patch (see k_strip_index).
+__global__ void k_patch_boxes(int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                              const int64_t *__restrict__ poff, int n_patches, unsigned long long *__restrict__ box) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = i < n;
+    double v[3] = {0.0, 0.0, 0.0};
+    int p = -1;
+    bool off_sphere = false;
+    if (ok) {
+        v[0] = x[i]; v[1] = y[i]; v[2] = z[i];
+        p = segment_of(poff, n_patches, i);
+        const double n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+        off_sphere = !(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL);
+    }
+    if (__builtin_amdgcn_ballot_w64(off_sphere) != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&box[(size_t)6 * n_patches], 1ull);
+    const int p0 = __builtin_amdgcn_readfirstlane(p);
+    if (__builtin_amdgcn_ballot_w64(p != p0) == 0ull) {
+        if (p0 < 0) return;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            unsigned long long lo = sortable_of(v[a]), hi = lo;
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicMin(&box[(size_t)6 * p0 + a], lo);
+                atomicMax(&box[(size_t)6 * p0 + 3 + a], hi);
+            }
+        }
+    } else if (ok) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&box[(size_t)6 * p + a], sortable_of(v[a]));
+            atomicMax(&box[(size_t)6 * p + 3 + a], sortable_of(v[a]));
+        }
+    }
+}
+
 inline int64_t seg_len(const yawhip_catalog *c, int patch, int k) {
     const int kk = c->nb == 1 ? 0 : k;
     const int64_t i = (int64_t)patch * c->nb + kk;
     return c->h_off[i + 1] - c->h_off[i];
+}
+
+// Build one strip layout of a catalogue from its resident (patch, bin, u) copy: orientation o = sort axis inside a run,
+// strips of the global grid along (o + 2) % 3; seg = groups are the (patch, bin) segments instead of the patches.
+int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
+    StripLayout &L = seg ? c->seg[o] : c->strips[o];
+    if (L.built) return YAWHIP_OK;
+    const int64_t n = c->n, nseg = (int64_t)c->n_patches * c->nb;
+    const int n_groups = seg ? (int)nseg : c->n_patches;
+    const bool want_bins = !seg && c->nb > 1;
+    const double width = c->strip_width;
+    const int saxis = (o + 2) % 3;  // z -> y, y -> x, x -> z
+    std::vector<int64_t> h_poff((size_t)n_groups + 1);
+    for (int g = 0; g <= n_groups; ++g) h_poff[(size_t)g] = seg ? c->h_off[(size_t)g] : c->h_off[(size_t)g * c->nb];
+    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    uint32_t *perm = nullptr, *perm2 = nullptr, *run = nullptr, *run_sorted = nullptr;
+    int32_t *gidx = nullptr, *lohi = nullptr;
+    int64_t *poff = nullptr;
+    auto bail = [&](hipError_t err, const char *what) {
+        for (void *q : {(void *)perm, (void *)perm2, (void *)run, (void *)run_sorted, (void *)gidx, (void *)lohi, (void *)poff})
+            if (q) (void)hipFree(q);
+        if (err == hipSuccess) return (int)YAWHIP_OK;
+        L.release();
+        return fail(err == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "strip layout (%s) failed: %s", what,
+                    hipGetErrorString(err));
+    };
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int32_t> h_lohi((size_t)2 * n_groups);
+    for (int g = 0; g < n_groups; ++g) { h_lohi[(size_t)2 * g] = INT32_MAX; h_lohi[(size_t)2 * g + 1] = INT32_MIN; }
+    const size_t n1 = (size_t)std::max<int64_t>(n, 1);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&poff), (size_t)(n_groups + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&lohi), (size_t)2 * n_groups * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&gidx), n1 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm), n1 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm2), n1 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run), n1 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&run_sorted), n1 * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(poff, h_poff.data(), (size_t)(n_groups + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(lohi, h_lohi.data(), (size_t)2 * n_groups * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return bail(e, "strip tables");
+    const unsigned ngrid = (unsigned)((n1 + 255) / 256);
+    // grid index of every object, first / last occupied strip of every group
+    hipLaunchKernelGGL(k_strip_index, dim3(ngrid), dim3(256), 0, ctx->stream, n, key_of(c->x, c->y, c->z, saxis), width, poff,
+                       n_groups, gidx, lohi);
+    e = hipMemcpyAsync(h_lohi.data(), lohi, (size_t)2 * n_groups * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(e, "strip index");
+    std::vector<int64_t> vbase((size_t)n_groups + 1, 0), slo((size_t)n_groups, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        const bool any = h_poff[(size_t)g + 1] > h_poff[(size_t)g];
+        slo[(size_t)g] = any ? h_lohi[(size_t)2 * g] : 0;
+        vbase[(size_t)g + 1] = vbase[(size_t)g] + (any ? (int64_t)h_lohi[(size_t)2 * g + 1] - h_lohi[(size_t)2 * g] + 1 : 0);
+    }
+    const int64_t n_runs = vbase[(size_t)n_groups];
+    if (n_runs >= (1ll << 31)) return bail(hipErrorInvalidValue, "too many strip runs");
+    int run_bits = 1;
+    while ((1ll << run_bits) < n_runs) ++run_bits;
+    e = hipMalloc(reinterpret_cast<void **>(&L.d_vbase), (size_t)(n_groups + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_slo), (size_t)std::max(n_groups, 1) * sizeof(int64_t));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(L.d_vbase, vbase.data(), (size_t)(n_groups + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(L.d_slo, slo.data(), (size_t)n_groups * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    // order along the sort axis inside every group, then group by run (unique keys (run, rank): no reliance on
+    // the stability of the sort)
+    if (e == hipSuccess) e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(c->x, c->y, c->z, o), poff, n_groups, perm);
+    if (e != hipSuccess) return bail(e, "group sort");
+    hipLaunchKernelGGL(k_run_of, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, gidx, poff, n_groups, L.d_vbase, L.d_slo, run);
+    e = yawsort::sort_runs(ctx->sort_ws, ctx->stream, n, run, perm, run_bits, perm2, run_sorted);
+    if (e != hipSuccess) return bail(e, "run sort");
+    e = hipMalloc(reinterpret_cast<void **>(&L.x), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.y), col);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
+    if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
+    if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), n1 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
+    if (e != hipSuccess) return bail(e, "strip layout");
+    hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->x, c->y, c->z, c->w, L.x, L.y, L.z, L.w);
+    if (want_bins)
+        hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, c->nb, L.k);
+    hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
+                       L.off);
+    std::vector<int64_t> voff((size_t)n_runs + 1);
+    e = hipMemcpyAsync(voff.data(), L.off, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(e, "run offsets");
+    // small per-run tables the item builder walks on the device
+    for (int ri = 0; ri < 3; ++ri) {
+        const int64_t tile = (int64_t)MWG << ri;
+        L.h_tiles[ri].assign((size_t)n_runs + 1, 0);
+        for (int64_t r = 0; r < n_runs; ++r)
+            L.h_tiles[ri][(size_t)r + 1] = L.h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(L.d_tiles[ri], L.h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
+                               hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(e, "tile tables");
+    L.h_off = std::move(voff);
+    L.h_vbase = std::move(vbase);
+    L.h_slo = std::move(slo);
+    L.n_groups = n_groups;
+    L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) +
+                     (4 * (n_runs + 1) + 2 * (int64_t)n_groups + 1) * (int64_t)sizeof(int64_t);
+    c->device_bytes += L.device_bytes;
+    L.built = true;
+    return bail(hipSuccess, "");
 }
 
 }  // namespace
@@ -1379,6 +1574,7 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_cprefix.release();
     ctx->d_kept.release();
     ctx->d_jobwork.release();
+    ctx->d_tabs.release();
     ctx->sort_ws.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1416,8 +1612,17 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->debug_no_hits = value != 0;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "auto_orient")) {
+        ctx->auto_orient = value != 0;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "flush_stages_log2")) {
+        if (value < 0 || value > 17) return fail(YAWHIP_ERR_INVALID, "flush_stages_log2 must be in [0, 17]");
+        ctx->flush_log2 = (int)value;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "kernel")) {
-        if (value < YAWHIP_KERNEL_AUTO || value > YAWHIP_KERNEL_SWEEP)
+        if (value < YAWHIP_KERNEL_AUTO || value > YAWHIP_KERNEL_BAND)
             return fail(YAWHIP_ERR_INVALID, "unknown kernel id %lld", (long long)value);
         ctx->default_kernel = (int)value;
         return YAWHIP_OK;
@@ -1460,20 +1665,16 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     c->nb = n_bins_or_1;
     c->axis = sort_axis;
     c->h_off.assign(offsets, offsets + nseg + 1);
-    for (int64_t i = 0; i < n && c->unit_norm; ++i) {
-        const double n2 = x[i] * x[i] + y[i] * y[i] + z[i] * z[i];
-        if (!(n2 > 1.0 - UNIT_NORM_TOL && n2 < 1.0 + UNIT_NORM_TOL)) c->unit_norm = false;
-    }
     // Library-private order: the columns go to the device as they are and are ordered there (rocPRIM radix sorts,
-    // yawhip_sort.hip): ascending along the sort axis inside every (patch, bin) segment, and the strip layout.
+    // yawhip_sort.hip): ascending along the sort axis inside every (patch, bin) segment. The strip layouts are derived
+    // from this resident copy (build_strip_layout), the one of the catalogue's own sort axis right away.
     const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
     double *rx = nullptr, *ry = nullptr, *rz = nullptr, *rw = nullptr;  // raw columns (temporary)
-    uint32_t *perm = nullptr, *perm2 = nullptr, *run = nullptr, *run_sorted = nullptr;
-    int32_t *gidx = nullptr, *lohi = nullptr;
+    uint32_t *perm = nullptr;
     int64_t *poff = nullptr;
+    unsigned long long *box = nullptr;  // [P][6] sortable images of min / max per axis, [6 P]: violations of the unit norm
     auto free_tmp = [&]() {
-        for (void *q : {(void *)rx, (void *)ry, (void *)rz, (void *)rw, (void *)perm, (void *)perm2, (void *)run,
-                        (void *)run_sorted, (void *)gidx, (void *)lohi, (void *)poff})
+        for (void *q : {(void *)rx, (void *)ry, (void *)rz, (void *)rw, (void *)perm, (void *)poff, (void *)box})
             if (q) (void)hipFree(q);
     };
     auto bail = [&](hipError_t err, const char *what) {
@@ -1482,6 +1683,15 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         return fail(err == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "catalog upload (%s) failed: %s", what,
                     hipGetErrorString(err));
     };
+    std::vector<int64_t> h_poff((size_t)n_patches + 1);
+    for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
+    std::vector<unsigned long long> h_box((size_t)6 * n_patches + 1);
+    for (int p = 0; p < n_patches; ++p)
+        for (int a = 0; a < 3; ++a) {
+            h_box[(size_t)6 * p + a] = sortable_of(4.0);       // running minimum
+            h_box[(size_t)6 * p + 3 + a] = sortable_of(-4.0);  // running maximum
+        }
+    h_box[(size_t)6 * n_patches] = 0ull;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->x), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->y), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->z), col);
@@ -1492,6 +1702,8 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&rz), col);
     if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&rw), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&perm), (size_t)std::max<int64_t>(n, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&poff), (size_t)(n_patches + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&box), h_box.size() * sizeof(unsigned long long));
     if (e == hipSuccess && n > 0) {
         e = hipMemcpyAsync(rx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ry, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -1500,119 +1712,39 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(c->off, offsets, (size_t)(nseg + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(poff, h_poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(box, h_box.data(), h_box.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return bail(e, "columns");
     const unsigned ngrid = (unsigned)((std::max<int64_t>(n, 1) + 255) / 256);
     if (n > 0) {
+        // bounding box of every patch (the orientation of a job follows from the boxes of its two patches) and the
+        // unit-norm check of the pre-filter, both on the device
+        hipLaunchKernelGGL(k_patch_boxes, dim3(ngrid), dim3(256), 0, ctx->stream, n, rx, ry, rz, poff, n_patches, box);
         e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(rx, ry, rz, sort_axis), c->off, nseg, perm);
         if (e != hipSuccess) return bail(e, "segment sort");
         hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, rx, ry, rz, rw, c->x, c->y, c->z, c->w);
         if ((e = hipGetLastError()) != hipSuccess) return bail(e, "gather");
-    }
-    c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
-    // One strip layout: groups = patches (bins merged, bin id per object) or (patch, bin) segments.
-    const double width = ctx->strip_width;
-    const int saxis = (sort_axis + 2) % 3;  // z -> y, y -> x, x -> z
-    int layout_rc = YAWHIP_OK;
-    auto bail_rc = [&](hipError_t err, const char *what) { layout_rc = bail(err, what); return false; };
-    auto build_layout = [&](StripLayout &L, const int64_t *goff, int n_patches, bool want_bins) -> bool {
-        std::vector<int64_t> h_poff(goff, goff + n_patches + 1);
-        if (poff) (void)hipFree(poff);
-        if (lohi) (void)hipFree(lohi);
-        poff = nullptr;
-        lohi = nullptr;
-        std::vector<int32_t> h_lohi((size_t)2 * n_patches);
-        for (int p = 0; p < n_patches; ++p) { h_lohi[(size_t)2 * p] = INT32_MAX; h_lohi[(size_t)2 * p + 1] = INT32_MIN; }
-        e = hipMalloc(reinterpret_cast<void **>(&poff), (size_t)(n_patches + 1) * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&lohi), (size_t)2 * n_patches * sizeof(int32_t));
-        if (e == hipSuccess && !gidx) e = hipMalloc(reinterpret_cast<void **>(&gidx), (size_t)n * sizeof(int32_t));
-        if (e == hipSuccess && !perm2) e = hipMalloc(reinterpret_cast<void **>(&perm2), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess && !run) e = hipMalloc(reinterpret_cast<void **>(&run), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess && !run_sorted) e = hipMalloc(reinterpret_cast<void **>(&run_sorted), (size_t)n * sizeof(uint32_t));
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(poff, h_poff.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(lohi, h_lohi.data(), (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) return bail_rc(e, "strip tables");
-        // grid index of every object, first / last occupied strip of every patch
-        hipLaunchKernelGGL(k_strip_index, dim3(ngrid), dim3(256), 0, ctx->stream, n, key_of(rx, ry, rz, saxis), width, poff,
-                           n_patches, gidx, lohi);
-        e = hipMemcpyAsync(h_lohi.data(), lohi, (size_t)2 * n_patches * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return bail_rc(e, "strip index");
-        std::vector<int64_t> vbase((size_t)n_patches + 1, 0), slo((size_t)n_patches, 0);
-        for (int p = 0; p < n_patches; ++p) {
-            const bool any = h_poff[(size_t)p + 1] > h_poff[(size_t)p];
-            slo[(size_t)p] = any ? h_lohi[(size_t)2 * p] : 0;
-            vbase[(size_t)p + 1] = vbase[(size_t)p] + (any ? (int64_t)h_lohi[(size_t)2 * p + 1] - h_lohi[(size_t)2 * p] + 1 : 0);
-        }
-        const int64_t n_runs = vbase[(size_t)n_patches];
-        if (n_runs >= (1ll << 31)) return bail_rc(hipErrorInvalidValue, "too many strip runs");
-        int run_bits = 1;
-        while ((1ll << run_bits) < n_runs) ++run_bits;
-        e = hipMalloc(reinterpret_cast<void **>(&L.d_vbase), (size_t)(n_patches + 1) * sizeof(int64_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_slo), (size_t)n_patches * sizeof(int64_t));
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(L.d_vbase, vbase.data(), (size_t)(n_patches + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(L.d_slo, slo.data(), (size_t)n_patches * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        // order along the sort axis inside every patch, then group by run (unique keys (run, rank): no reliance on
-        // the stability of the sort)
-        if (e == hipSuccess) e = yawsort::sort_segments(ctx->sort_ws, ctx->stream, n, key_of(rx, ry, rz, sort_axis), poff, n_patches, perm);
-        if (e != hipSuccess) return bail_rc(e, "patch sort");
-        hipLaunchKernelGGL(k_run_of, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm, gidx, poff, n_patches, L.d_vbase, L.d_slo, run);
-        e = yawsort::sort_runs(ctx->sort_ws, ctx->stream, n, run, perm, run_bits, perm2, run_sorted);
-        if (e != hipSuccess) return bail_rc(e, "run sort");
-        e = hipMalloc(reinterpret_cast<void **>(&L.x), col);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.y), col);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
-        if (e == hipSuccess && w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
-        if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), (size_t)n * sizeof(int32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
-        if (e != hipSuccess) return bail_rc(e, "strip layout");
-        hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, rx, ry, rz, rw, L.x, L.y, L.z, L.w);
-        if (want_bins)
-            hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, n_bins_or_1, L.k);
-        hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
-                           L.off);
-        std::vector<int64_t> voff((size_t)n_runs + 1);
-        e = hipMemcpyAsync(voff.data(), L.off, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return bail_rc(e, "run offsets");
-        // small per-run tables the item builder walks on the device
-        for (int ri = 0; ri < 3; ++ri) {
-            const int64_t tile = (int64_t)MWG << ri;
-            L.h_tiles[ri].assign((size_t)n_runs + 1, 0);
-            for (int64_t r = 0; r < n_runs; ++r)
-                L.h_tiles[ri][(size_t)r + 1] = L.h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(L.d_tiles[ri], L.h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
-                                   hipMemcpyHostToDevice, ctx->stream);
-        }
-        if (e != hipSuccess) return bail_rc(e, "tile tables");
-        L.h_off = std::move(voff);
-        L.h_vbase = std::move(vbase);
-        L.h_slo = std::move(slo);
-        L.n_groups = n_patches;
-        c->device_bytes += (int64_t)col * (w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) +
-                           (4 * (n_runs + 1) + 2 * (int64_t)n_patches + 1) * (int64_t)sizeof(int64_t);
-            return true;
-    };
-    if (c->unit_norm && n > 0) {
-        // strips are cells of a global grid along strip_axis, so that runs of different catalogues can be paired by
-        // their grid index alone
-        std::vector<int64_t> h_poff((size_t)n_patches + 1);
-        for (int p = 0; p <= n_patches; ++p) h_poff[(size_t)p] = offsets[(int64_t)p * n_bins_or_1];
-        if (!build_layout(c->strips, h_poff.data(), n_patches, n_bins_or_1 > 1)) return layout_rc;
-        // per-segment layout of a binned catalogue (used when the lane side of a binned x binned count is dense)
-        if (n_bins_or_1 > 1)
-            if (!build_layout(c->seg, offsets, (int)nseg, false)) return layout_rc;
-        c->strip_width = width;
-        c->strip_axis = saxis;
+        e = hipMemcpyAsync(h_box.data(), box, h_box.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) return bail(e, "patch boxes");
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(e, "finish");
     free_tmp();
+    c->unit_norm = h_box[(size_t)6 * n_patches] == 0ull;
+    c->h_box.resize((size_t)6 * n_patches);
+    for (size_t i = 0; i < c->h_box.size(); ++i) c->h_box[i] = double_of(h_box[i]);
+    c->device_bytes = (int64_t)col * (w ? 4 : 3) + (nseg + 1) * (int64_t)sizeof(int64_t);
+    c->strip_width = ctx->strip_width;
+    c->has_strips = c->unit_norm && n > 0;
+    if (c->has_strips) {
+        const int rc = build_strip_layout(ctx, c, sort_axis, false);
+        if (rc != YAWHIP_OK) {
+            yawhip_catalog_free(c);
+            return rc;
+        }
+    }
     if (ctx->sort_ws.cap > ((size_t)1 << 25)) ctx->sort_ws.release();  // ~30 bytes per object: keep only small workspaces
     *out = c;
     return YAWHIP_OK;
@@ -1626,8 +1758,10 @@ int yawhip_catalog_free(yawhip_catalog *c) {
     if (c->z) (void)hipFree(c->z);
     if (c->w) (void)hipFree(c->w);
     if (c->off) (void)hipFree(c->off);
-    c->strips.release();
-    c->seg.release();
+    for (int o = 0; o < 3; ++o) {
+        c->strips[o].release();
+        c->seg[o].release();
+    }
     delete c;
     return YAWHIP_OK;
 }
@@ -1662,15 +1796,17 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (jobs[2 * j] < 0 || jobs[2 * j] >= c1->n_patches || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= c1->n_patches)
             return fail(YAWHIP_ERR_INVALID, "job %d has a patch id outside [0,%d)", j, c1->n_patches);
     if (kernel == YAWHIP_KERNEL_AUTO) kernel = ctx->default_kernel;
-    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_SWEEP;
-    if (kernel < YAWHIP_KERNEL_EXACT || kernel > YAWHIP_KERNEL_SWEEP)
+    if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_BAND;
+    if (kernel < YAWHIP_KERNEL_EXACT || kernel > YAWHIP_KERNEL_BAND)
         return fail(YAWHIP_ERR_INVALID, "unknown kernel id %d", kernel);
     // the FP32 pre-filter assumes unit vectors; anything else is evaluated pair by pair in FP64
     const bool unit = c1->unit_norm && c2->unit_norm;
     if (kernel == YAWHIP_KERNEL_FILTER && !unit) kernel = YAWHIP_KERNEL_EXACT;
     // the window search compares the sorted coordinate of both sides: the axes must agree
-    if (kernel == YAWHIP_KERNEL_SWEEP && c1->axis != c2->axis) kernel = unit ? YAWHIP_KERNEL_FILTER : YAWHIP_KERNEL_EXACT;
-    const bool sweep = kernel == YAWHIP_KERNEL_SWEEP;
+    if ((kernel == YAWHIP_KERNEL_SWEEP || kernel == YAWHIP_KERNEL_BAND) && c1->axis != c2->axis)
+        kernel = unit ? YAWHIP_KERNEL_FILTER : YAWHIP_KERNEL_EXACT;
+    const bool band = kernel == YAWHIP_KERNEL_BAND;  // exact FP64 on per-object bands: needs no unit vectors
+    const bool sweep = kernel == YAWHIP_KERNEL_SWEEP || band;
     const bool filter = unit && kernel != YAWHIP_KERNEL_EXACT;
 
     const int nf = n_edges - 1;
@@ -1687,29 +1823,64 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // form (one item for all bins, strip layouts on both sides) serves c1 binned x c2 unbinned, i.e. every
     // count of a cross-correlation.
     const bool weighted_any = (c1->w != nullptr) || (c2->w != nullptr);
-    const bool lean = sweep && filter;
+    const bool lean = sweep && (filter || band);  // single-wave workgroups on windowed items (k_count_merged / k_count_band)
     double rwin_max = 0.0;  // widest window half width over the bins
     for (int k = 0; k < n_bins; ++k)
         rwin_max = std::max(rwin_max, std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15);
     // strip pairing pays while a run has few partner runs; for separations far beyond the grid spacing the
     // ordinary (patch, bin) layout is used instead
-    const bool strips = lean && c1->strips.x != nullptr && c2->strips.x != nullptr && c1->strip_width == c2->strip_width &&
-                        c1->strip_axis == c2->strip_axis &&
+    const bool strips = lean && c1->has_strips && c2->has_strips && c1->strip_width == c2->strip_width &&
                         (c1->strip_width <= 0.0 || rwin_max / c1->strip_width <= (double)MAX_STRIP_REACH);
-    // mode 3: binned x binned on the per-segment strip layouts (built at upload for dense catalogues only): ordinary
-    // (job, bin) items whose lane tiles and windows come from (patch, bin, strip) runs
-    // -- it pays when the lane side is dense: runs of at least a few lane tiles per (patch, bin, strip)
-    const bool seg_ok = strips && c1->seg.x != nullptr && c2->seg.x != nullptr && c1->nb == n_bins && c2->nb == n_bins && ctx->seg_strips &&
-                        c2->n / std::max<int64_t>(c2->seg.h_vbase[(size_t)c2->seg.n_groups], 1) >= ctx->seg_min_run;
+    // mode 3: binned x binned on the per-segment strip layouts: ordinary (job, bin) items whose lane tiles and windows
+    // come from (patch, bin, strip) runs -- it pays when the lane side is dense: runs of at least a few lane tiles per
+    // (patch, bin, strip); estimated from the patch-level layout the upload built (B times as many runs)
+    bool seg_ok = false;
+    if (strips && c1->nb == n_bins && c2->nb == n_bins && n_bins > 1 && ctx->seg_strips) {
+        const StripLayout &base2 = c2->strips[c2->axis];
+        const int64_t seg_runs = base2.h_vbase[(size_t)base2.n_groups] * (int64_t)c2->nb;
+        seg_ok = c2->n / std::max<int64_t>(seg_runs, 1) >= ctx->seg_min_run;
+    }
     const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1 : (seg_ok ? 3 : 0);
     const bool merged = mode == 1;                // one item covers all bins, output slot = job
     const bool strip_items = mode != 0;           // items come from strip runs (k_build_items_strips)
-    const StripLayout &sl1 = mode == 3 ? c1->seg : c1->strips, &sl2 = mode == 3 ? c2->seg : c2->strips;
+    // Orientation of every job: the (u, v) projection that compresses the sphere least around its two patches, i.e.
+    // the one that drops the coordinate w in which the patches lie farthest from the origin. (Projected along an
+    // axis the patches are nearly perpendicular to, objects pile up in (u, v) -- density grows like 1 / |w| -- and
+    // the opposite hemisphere folds onto the same cells: every u-window then holds several times the partners.)
+    std::vector<int32_t> orient((size_t)n_jobs, (int32_t)c1->axis);
+    const StripLayout *L1[3] = {nullptr, nullptr, nullptr}, *L2[3] = {nullptr, nullptr, nullptr};
+    if (strip_items) {
+        bool need[3] = {false, false, false};
+        for (int j = 0; j < n_jobs; ++j) {
+            if (ctx->auto_orient) {
+                const double *b1 = &c1->h_box[(size_t)6 * jobs[2 * j]], *b2 = &c2->h_box[(size_t)6 * jobs[2 * j + 1]];
+                double best = -1.0;
+                int wax = (c1->axis + 1) % 3;
+                for (int a = 0; a < 3; ++a) {
+                    const double m = (b1[a] <= b1[3 + a] ? 0.5 * (b1[a] + b1[3 + a]) : 0.0) +
+                                     (b2[a] <= b2[3 + a] ? 0.5 * (b2[a] + b2[3 + a]) : 0.0);
+                    if (std::fabs(m) > best) { best = std::fabs(m); wax = a; }
+                }
+                orient[(size_t)j] = (wax + 2) % 3;  // sort axis u whose dropped axis (u + 1) % 3 is wax
+            }
+            need[orient[(size_t)j]] = true;
+        }
+        for (int o = 0; o < 3; ++o) {
+            if (!need[o]) continue;
+            int rc = build_strip_layout(ctx, const_cast<yawhip_catalog *>(c1), o, mode == 3);
+            if (rc == YAWHIP_OK && c2 != c1) rc = build_strip_layout(ctx, const_cast<yawhip_catalog *>(c2), o, mode == 3);
+            if (rc != YAWHIP_OK) return rc;
+            L1[o] = mode == 3 ? &c1->seg[o] : &c1->strips[o];
+            L2[o] = mode == 3 ? &c2->seg[o] : &c2->strips[o];
+        }
+    }
     int R = ctx->tile_r;
     if (R == 0) {
         int64_t max_seg = 0;
         if (strip_items) {  // lanes hold runs of a strip layout: their typical (mean) length decides
-            const int64_t n_runs = sl2.h_vbase[(size_t)sl2.n_groups];
+            int64_t n_runs = 1;
+            for (int o = 0; o < 3; ++o)
+                if (L2[o]) n_runs = std::max(n_runs, L2[o]->h_vbase[(size_t)L2[o]->n_groups]);
             max_seg = c2->n / std::max<int64_t>(n_runs, 1);
             if (mode == 3) max_seg = std::max<int64_t>(max_seg, 4 * MWG * 2);  // at least two objects per lane: per-bin runs are
                                                                                 // sparse, the per-item cost outweighs the wider window
@@ -1721,13 +1892,19 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         R = max_seg >= 8 * wg * 4 ? 4 : (max_seg >= 4 * wg * 2 ? 2 : 1);
         if (strip_items && R > 2) R = 2;  // on strip runs two objects per lane beat four at every size measured (10M: 2.25 / 2.5 ms, 50M: 68 / 72 ms)
     }
+    if (band && R > 2) R = 2;  // the band kernel keeps its lane objects in float64 registers: one or two per lane
     const int64_t tile = (int64_t)(lean ? MWG : WG) * R;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
                               (size_t)lean_bins * nf * (weighted_any ? 8 * (MWG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
                               (size_t)MWG * sizeof(unsigned int) + 16;
-    if (lean && lds_merged > (size_t)ctx->lds_limit)
-        return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", lds_merged);
+    const size_t lds_band = (size_t)BCAP * sizeof(double) * (weighted_any ? 4 : 3) + (size_t)lean_bins * n_edges * sizeof(double) +
+                            (size_t)lean_bins * nf * (weighted_any ? 8 : 4) + (merged ? (size_t)BCAP * sizeof(int) : 0) + 16;
+    if (lean && (band ? lds_band : lds_merged) > (size_t)ctx->lds_limit)
+        return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band : lds_merged);
+    bool uniform_t = true;  // every bin has the same threshold row (angular scales)
+    for (int k = 1; k < n_bins && uniform_t; ++k)
+        uniform_t = memcmp(t, t + (size_t)k * n_edges, sizeof(double) * n_edges) == 0;
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
@@ -1755,10 +1932,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                 sjobs[(size_t)2 * sj + 1] = mode == 3 ? jobs[2 * j + 1] * n_bins + k : jobs[2 * j + 1];
             }
         prefix.resize((size_t)n_sjobs + 1);
-        job_runs.assign((size_t)2 * n_sjobs, 0);
-        const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
+        job_runs.assign((size_t)3 * n_sjobs, 0);
         for (int64_t j = 0; j < n_sjobs; ++j) {
             const int p = sjobs[(size_t)2 * j], q = sjobs[(size_t)2 * j + 1];
+            const int o = orient[(size_t)(mode == 3 ? j / n_bins : j)];
+            const StripLayout &sl1 = *L1[o], &sl2 = *L2[o];
+            const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
+            job_runs[(size_t)3 * j + 2] = o;
             prefix[(size_t)j] = n_items;
             // strips of q whose grid index lies within `reach` of the strips group p occupies
             const int64_t cnt1 = sl1.h_vbase[(size_t)p + 1] - sl1.h_vbase[(size_t)p], lo1 = sl1.h_slo[(size_t)p];
@@ -1766,8 +1946,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             const int64_t s_lo = std::max<int64_t>(lo1 - reach - lo2, 0), s_hi = std::min<int64_t>(lo1 + cnt1 - 1 + reach - lo2, cnt2 - 1);
             if (cnt1 > 0 && s_hi >= s_lo) {
                 const int64_t r0 = sl2.h_vbase[(size_t)q] + s_lo;
-                job_runs[(size_t)2 * j] = (int32_t)s_lo;
-                job_runs[(size_t)2 * j + 1] = (int32_t)(s_hi - s_lo + 1);
+                job_runs[(size_t)3 * j] = (int32_t)s_lo;
+                job_runs[(size_t)3 * j + 1] = (int32_t)(s_hi - s_lo + 1);
                 n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * (2 * reach + 1);
             }
         }
@@ -1797,7 +1977,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool run_weighted = weighted && want_sums;
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
-    HIP_TRY(ctx->d_jobs.reserve((size_t)4 * std::max<int64_t>(n_jobs, n_sjobs)));
+    HIP_TRY(ctx->d_jobs.reserve((size_t)5 * std::max<int64_t>(n_jobs, n_sjobs)));
     HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
     HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
     HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
@@ -1815,7 +1995,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
     if (strip_items) {
         HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, sjobs.data(), sizeof(int32_t) * 2 * n_sjobs, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, job_runs.data(), sizeof(int32_t) * 2 * n_sjobs,
+        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, job_runs.data(), sizeof(int32_t) * 3 * n_sjobs,
                                hipMemcpyHostToDevice, ctx->stream));
     } else {
         HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
@@ -1826,6 +2006,22 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * 3 * n_bins, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_sums.ptr, 0, sizeof(double) * n_out, ctx->stream));
+    // layout table of the call: [o] = c1, [3 + o] = c2 for orientation o (plain layouts: entries 0 and 3)
+    DevTab h_tabs[6];
+    memset(h_tabs, 0, sizeof h_tabs);
+    if (strip_items) {
+        for (int o = 0; o < 3; ++o) {
+            if (!L1[o]) continue;
+            const StripLayout &a = *L1[o], &b = *L2[o];
+            h_tabs[o] = DevTab{a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx], o, 0};
+            h_tabs[3 + o] = DevTab{b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx], o, 0};
+        }
+    } else {
+        h_tabs[0] = DevTab{c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, c1->axis, 0};
+        h_tabs[3] = DevTab{c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, c2->axis, 0};
+    }
+    HIP_TRY(ctx->d_tabs.reserve(6));
+    HIP_TRY(hipMemcpyAsync(ctx->d_tabs.ptr, h_tabs, sizeof h_tabs, hipMemcpyHostToDevice, ctx->stream));
 
     // LDS: two stages + thresholds + histogram(s)
     const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
@@ -1838,13 +2034,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (n_pot >= (1ll << 31))
             return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
         HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
-        HIP_TRY(ctx->d_ctr.reserve(4));
+        HIP_TRY(ctx->d_ctr.reserve(N_CTR));
         HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
         std::vector<double> rwin((size_t)n_bins);
         for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
         if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
         HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, 2 * sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, (band ? N_CTR : 2) * sizeof(unsigned long long), ctx->stream));
         unsigned char *kept_flags = nullptr;  // weighted runs of the culling builders: which potential items write a slab
         if (run_weighted && sweep) {
             HIP_TRY(ctx->d_kept.reserve((size_t)n_pot));
@@ -1853,9 +2049,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         }
         const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
         if (strip_items)
-            hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream,
-                               StripView{key_of(sl1.x, sl1.y, sl1.z, c1->axis), sl1.off, sl1.d_vbase, sl1.d_slo, sl1.d_tiles[tile_idx]},
-                               StripView{key_of(sl2.x, sl2.y, sl2.z, c2->axis), sl2.off, sl2.d_vbase, sl2.d_slo, sl2.d_tiles[tile_idx]},
+            hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, ctx->d_tabs.ptr,
                                ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, ctx->d_prefix.ptr, (int)n_sjobs, reach,
                                (int)tile, rwin_max, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
@@ -1872,7 +2066,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         // number the builder kept (device counter): no host round trip between the two kernels.
         HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
         n_items = n_pot;
-        if (strip_items && n_pot > SYNC_GRID_MIN_ITEMS) {
+        if (strip_items && !band && n_pot > SYNC_GRID_MIN_ITEMS) {
             // The strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
             // dispatching workgroups that exit at once (measured at 1.6e6 potential items, 10M x 10M), more than
             // this round trip (~0.05 ms) costs. Small calls (one GPU's share of a sharded job list) skip it.
@@ -1916,11 +2110,63 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         return hipGetLastError();
     };
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
-    if (n_items > 0 && lean) {
-        const MergedView mv = strip_items ? MergedView{sl1.x, sl1.y, sl1.z, sl1.w, merged ? sl1.k : nullptr}
-                                          : MergedView{c1->x, c1->y, c1->z, c1->w, nullptr};
-        const CatView lanes = strip_items ? CatView{sl2.x, sl2.y, sl2.z, sl2.w, sl2.off, 1, key_of(sl2.x, sl2.y, sl2.z, c2->axis), c2->axis}
-                                          : view_of(c2);
+    std::vector<unsigned long long> eval_ctr;
+    if (n_items > 0 && lean && band) {
+        // Grid from the number of POTENTIAL items (known on the host); the kernel reads the number the builder kept
+        // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
+        // The strip builder keeps about one potential item in five, ordinary items are all kept.
+        int64_t grid = strip_items && n_pot > 65536 ? n_pot / 4 : n_pot;
+        grid = std::min<int64_t>((grid + 7) & ~7ll, 1ll << 22);
+        const unsigned flush_mask = (1u << ctx->flush_log2) - 1u;
+        auto launch_band = [&](bool wgt) -> hipError_t {
+#define YAW_LAUNCH_BAND(RR, WW, NN, MM, UU)                                                                           \
+    do {                                                                                                              \
+        auto kern = k_count_band<RR, WW, NN, MM, UU>;                                                                 \
+        if (lds_band > 64 * 1024) {                                                                                   \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_band);           \
+            if (ea != hipSuccess) return ea;                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
+                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_rwin.ptr, flush_mask, ctx->d_counts.ptr,             \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
+    } while (0)
+#define YAW_LAUNCH_BAND_R(WW, NN, MM, UU)                                                                             \
+    do {                                                                                                              \
+        if (R == 1) YAW_LAUNCH_BAND(1, WW, NN, MM, UU); else YAW_LAUNCH_BAND(2, WW, NN, MM, UU);                      \
+    } while (0)
+#define YAW_LAUNCH_BAND_M(WW, NN)                                                                                     \
+    do {                                                                                                              \
+        if (!merged) YAW_LAUNCH_BAND_R(WW, NN, false, true);                                                          \
+        else if (uniform_t) YAW_LAUNCH_BAND_R(WW, NN, true, true);                                                    \
+        else YAW_LAUNCH_BAND_R(WW, NN, true, false);                                                                  \
+    } while (0)
+            const bool nf1 = nf == 1;
+            if (wgt) {
+                if (nf1) YAW_LAUNCH_BAND_M(true, true); else YAW_LAUNCH_BAND_M(true, false);
+            } else {
+                if (nf1) YAW_LAUNCH_BAND_M(false, true); else YAW_LAUNCH_BAND_M(false, false);
+            }
+#undef YAW_LAUNCH_BAND_M
+#undef YAW_LAUNCH_BAND_R
+#undef YAW_LAUNCH_BAND
+            return hipGetLastError();
+        };
+        if (run_unweighted) {
+            HIP_TRY(launch_band(false));
+            ++launches;
+        }
+        if (run_weighted) {
+            HIP_TRY(launch_band(true));
+            ++launches;
+            HIP_TRY(reduce_partials(merged ? (int64_t)n_jobs : n_slots, slab));  // slabs are reduced per output slot
+            launches += 2;
+        }
+        if (stats) {
+            eval_ctr.resize(N_CTR);
+            HIP_TRY(hipMemcpyAsync(eval_ctr.data(), ctx->d_ctr.ptr, sizeof(unsigned long long) * N_CTR, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    } else if (n_items > 0 && lean) {
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = (1ll << 31) / MWG;  // at most 2^32 - 1 work-items per launch dimension
             for (int64_t base = 0; base < n_items; base += max_grid) {
@@ -1933,7 +2179,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_merged);         \
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
-        hipLaunchKernelGGL(kern, dim3(g), dim3(MWG), lds_merged, ctx->stream, mv, lanes, ctx->d_items.ptr,            \
+        hipLaunchKernelGGL(kern, dim3(g), dim3(MWG), lds_merged, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr,      \
                            n_bins, n_edges, ctx->d_t.ptr, ctx->d_dthr.ptr, ctx->d_rwin.ptr, base, ctx->d_counts.ptr,  \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
@@ -2009,6 +2255,11 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->count_ms = cms;
         stats->candidate_pairs = cand;
         stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
+        if (!eval_ctr.empty()) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
+            unsigned long long ev = 0;
+            for (int i = 0; i < EVAL_SLOTS; ++i) ev += eval_ctr[8 + 8 * (size_t)i];
+            stats->evaluated_pairs = (int64_t)ev;
+        }
         stats->algorithmic_bytes = abytes;
         stats->n_workgroups = n_pot > 0 ? (int64_t)ctr[0] : 0;
         stats->n_launches = launches;
