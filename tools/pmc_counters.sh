@@ -12,7 +12,7 @@ for p in ("p1", "p2"):
     dur = 0
     for f in glob.glob("$O/%s/*counter_collection.csv" % p):
         for r in csv.DictReader(open(f)):
-            if "k_count_merged" in r["Kernel_Name"]:
+            if "k_count_merged" in r["Kernel_Name"] or "k_count_band" in r["Kernel_Name"]:
                 seen.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                 dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     print("$TAG", p, "dur_ms", dur / 1e6, {k: f"{v[-1]:.4g}" for k, v in sorted(seen.items())})

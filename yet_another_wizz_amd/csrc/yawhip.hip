@@ -843,25 +843,62 @@ constexpr int BCAP = 160;  // window objects per LDS stage: 160 * 28 B + tables 
 constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
 constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries
 
+// LDS image of a band workgroup. The staged window lives in float64 SoA columns filled by LDS-DMA (global_load_lds_dwordx4:
+// 16 bytes per lane straight from HBM into LDS, no staging registers, no ds_write), one entry of slack per column for the
+// sentinel. The columns sit in a STATIC array at fixed offsets 2064 bytes apart, with the small tables in the gaps:
+//   * the walk addresses x, y, z and the bin id from one register with immediate offsets;
+//   * two ds_read_b64 less than 2041 bytes, or a multiple of 512 bytes, apart would be fused into ds_read2_b64 /
+//     ds_read2st64_b64, which take twice their LDS cycles.
+// Weights, edge tables and histograms too large for the gaps follow in dynamic LDS.
+constexpr int BCOL = (BCAP + 2) * 8;      // bytes of a float64 column (BCAP entries + sentinel, 16-byte multiple): 1296
+constexpr int BKCOL = (BCAP + 4) * 4;     // bytes of the bin-id column: 656
+constexpr int LDS_X = 0, LDS_K = LDS_X + BCOL, LDS_Y = 2064, LDS_H = LDS_Y + BCOL, LDS_Z = 4128, LDS_FIXED = LDS_Z + BCOL;
+constexpr int LDS_H_BYTES = LDS_Z - LDS_H - 256;  // room of the small histogram (the 64 dummy cells follow it): 496
+static_assert(LDS_K + BKCOL <= LDS_Y && LDS_H_BYTES >= 480, "band LDS image");
+__host__ __device__ inline bool band_small_hist(bool weighted, int nslots, int hp) { return (size_t)nslots * hp * (weighted ? 8 : 4) <= (size_t)LDS_H_BYTES; }
+// dynamic LDS bytes of a band workgroup (host and device agree through this one function)
+__host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp) {
+    const int nslots = nkb * (n_edges - 1);
+    return (weighted ? (size_t)BCOL : 0) + (need_thr ? (size_t)nkb * n_edges * sizeof(double) : 0) +
+           (band_small_hist(weighted, nslots, hp) ? 0 : (size_t)nslots * hp * (weighted ? 8 : 4)) + 16;
+}
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+__device__ __forceinline__ double lds_f64(unsigned addr) { return *(const __attribute__((address_space(3))) double *)(size_t)addr; }
+__device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribute__((address_space(3))) int *)(size_t)addr; }
+
 template <int R, bool WEIGHTED, bool NF1, bool MERGED, bool UNI>
 __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
-                                                   const double *__restrict__ rwin_k, unsigned flush_mask,
+                                                   const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
                                                    unsigned long long *__restrict__ out_counts,
                                                    double *__restrict__ partials,
                                                    unsigned long long *__restrict__ counters) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr bool NEED_THR = !NF1 || (MERGED && !UNI);  // edge table in LDS (else the two edges live in registers)
+    constexpr int HB = WEIGHTED ? 3 : 2;                 // log2 of the bytes of a histogram cell
+    __shared__ __attribute__((aligned(16))) unsigned char lds_fix[LDS_FIXED];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     const int nkb = MERGED ? n_bins : 1;  // bins one item can add to
-    const int nf = n_edges - 1;
+    const int nf = NF1 ? 1 : n_edges - 1;
     const int nslots = nkb * nf;
-    double *sx = reinterpret_cast<double *>(lds_raw);  // [BCAP] each
-    double *sy = sx + BCAP, *sz = sy + BCAP;
-    double *sw = sz + BCAP;                                                  // weighted only
-    double *thr = sz + (WEIGHTED ? 2 : 1) * BCAP;                            // [nkb][n_edges]
-    HistT *hist = reinterpret_cast<HistT *>(thr + (size_t)nkb * n_edges);    // [nkb][nf]
-    int *sk = reinterpret_cast<int *>(hist + nslots);                        // [BCAP] merged only
+    const int hp = 1 << hp_shift;  // copies of the histogram (lanes spread over them: fewer same-address LDS atomics)
+    double *sx = reinterpret_cast<double *>(lds_fix + LDS_X);
+    double *sy = reinterpret_cast<double *>(lds_fix + LDS_Y);
+    double *sz = reinterpret_cast<double *>(lds_fix + LDS_Z);
+    int *sk = reinterpret_cast<int *>(lds_fix + LDS_K);
+    unsigned char *p = lds_dyn;
+    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += BCOL;
+    double *thr = reinterpret_cast<double *>(p); if (NEED_THR) p += (size_t)nkb * n_edges * sizeof(double);   // [nkb][n_edges]
+    const bool small_hist = band_small_hist(WEIGHTED, nslots, hp);
+    HistT *hist = reinterpret_cast<HistT *>(small_hist ? lds_fix + LDS_H : p);                                // [nslots][hp]
+    unsigned int *dummy = reinterpret_cast<unsigned int *>(lds_fix + LDS_H + LDS_H_BYTES);                    // [64] one cell per lane for misses
     const int lane = threadIdx.x;
+    // LDS addresses (32 bit) the walk works with
+    const unsigned a_sx = (unsigned)(size_t)(lds_byte *)(lds_fix + LDS_X);
+    const unsigned a_sw = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
+    const unsigned a_cell = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist) + ((lane & (hp - 1)) << HB);  // this lane's copy of cell 0
+    const unsigned a_dummy = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(dummy + lane);
+    const int ksh = hp_shift + HB;                  // slot number -> byte offset of its first histogram cell
 
     const unsigned long long n_kept = counters[0];
     const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
@@ -873,13 +910,29 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
         const DevTab c1 = tabs[o], c2 = tabs[3 + o];  // wave-uniform: scalar loads
-        const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);
+        const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);  // sort-axis column of the stage
         const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
         const int64_t b0 = it.b0, nb_total = it.nb;
         const int64_t a_end = it.a0 + it.na;
 
-        // all global loads of the item back to back: lane objects, first stage, thresholds
+        __syncthreads();  // the previous item of this workgroup has left the LDS
+        // stage of the window -> LDS, 16 bytes per lane and instruction; lanes past the stage stay out of it
+        auto stage_in = [&](int64_t first, int n) {
+#pragma unroll
+            for (int c = 0; c < (BCAP + 127) / 128; ++c) {
+                const int e = c * 128 + 2 * lane;
+                if (e < n) {
+                    __builtin_amdgcn_global_load_lds(c1.x + b0 + first + e, sx + c * 128, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(c1.y + b0 + first + e, sy + c * 128, 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(c1.z + b0 + first + e, sz + c * 128, 16, 0, 0);
+                    if (WEIGHTED && c1.w) __builtin_amdgcn_global_load_lds(c1.w + b0 + first + e, sw + c * 128, 16, 0, 0);
+                }
+            }
+            if (MERGED && 4 * lane < n) __builtin_amdgcn_global_load_lds(c1.k + b0 + first + 4 * lane, sk, 16, 0, 0);
+        };
+        stage_in(0, (int)(nb_total < BCAP ? nb_total : BCAP));
+        // lane objects and thresholds while the stage is in flight
         double ax[R], ay[R], az[R], aw[R];
         bool ok[R];
 #pragma unroll
@@ -890,28 +943,14 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
             ax[r] = c2.x[ic]; ay[r] = c2.y[ic]; az[r] = c2.z[ic];
             aw[r] = (WEIGHTED && c2.w) ? c2.w[ic] : 1.0;
         }
-        constexpr int NPF = (BCAP + 63) / 64;
-        double fx[NPF], fy[NPF], fz[NPF], fw[NPF];
-        int fk[NPF];
-        auto fetch = [&](int64_t first) {  // stage starting at window entry `first` -> registers
-#pragma unroll
-            for (int f = 0; f < NPF; ++f) {
-                const int64_t e = first + f * 64 + lane;
-                const int64_t ic = b0 + (e < nb_total ? e : nb_total - 1);
-                fx[f] = c1.x[ic]; fy[f] = c1.y[ic]; fz[f] = c1.z[ic];
-                fk[f] = MERGED ? c1.k[ic] : 0;
-                fw[f] = (WEIGHTED && c1.w) ? c1.w[ic] : 1.0;
-            }
-        };
-        fetch(0);
-        __syncthreads();  // the previous item of this workgroup has left the LDS
-        for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
-        for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);
         double t_lo = 0.0, t_hi = 0.0;  // edges of the item's bin (or of every bin) in registers
         if (!MERGED || UNI) {
             t_lo = t[(int64_t)kfix * n_edges];
             t_hi = t[(int64_t)kfix * n_edges + n_edges - 1];
         }
+        if (NEED_THR)
+            for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
+        for (int e = lane; e < nslots * hp; e += 64) hist[e] = HistT(0);
         double klo[R], khi[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -920,9 +959,9 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
             khi[r] = ua + rwin;
         }
         unsigned int cnt1 = 0;             // NF1 && !MERGED: the item's only counter lives in a register
-        unsigned long long nev = 0;        // band entries this lane evaluated
+        unsigned int nev = 0;              // band entries this lane evaluated
         unsigned stage_no = 0;
-        auto flush = [&]() {  // LDS histogram -> global result (unweighted) / slab (weighted); called at the end of the item
+        auto flush = [&]() {  // LDS histogram -> global result (unweighted) / slab (weighted)
             if (NF1 && !MERGED && !WEIGHTED) {
                 if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)islot * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
                 cnt1 = 0;
@@ -930,86 +969,122 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
             }
             __syncthreads();
             for (int idx = lane; idx < nslots; idx += 64) {
-                if (WEIGHTED) {
-                    partials[(int64_t)it.pot * nslots + idx] = reinterpret_cast<double *>(hist)[idx];
-                } else {
-                    const unsigned int c = reinterpret_cast<unsigned int *>(hist)[idx];
-                    if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
-                    reinterpret_cast<unsigned int *>(hist)[idx] = 0u;
+                HistT c = HistT(0);
+                for (int h = 0; h < hp; ++h) {  // fixed order: reproducible weighted sums
+                    c += hist[idx * hp + h];
+                    hist[idx * hp + h] = HistT(0);
                 }
+                if (WEIGHTED) partials[(int64_t)it.pot * nslots + idx] = (double)c;
+                else if (c != HistT(0)) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
             }
         };
 
         for (int64_t st0 = 0; st0 < nb_total; st0 += BCAP, ++stage_no) {
             const int n = (int)(nb_total - st0 < BCAP ? nb_total - st0 : BCAP);
             if (st0 > 0) {
-                fetch(st0);
                 __syncthreads();  // every lane is done with the previous stage
+                stage_in(st0, n);
             }
-#pragma unroll
-            for (int f = 0; f < NPF; ++f) {
-                const int e = f * 64 + lane;
-                if (e < n) {
-                    sx[e] = fx[f]; sy[e] = fy[f]; sz[e] = fz[f];
-                    if (MERGED) sk[e] = fk[f];
-                    if (WEIGHTED) sw[e] = fw[f];
-                }
+            __syncthreads();  // the stage has landed (the compiler drains the LDS-DMA in front of the barrier)
+            if (lane == 0) {  // sentinel behind the stage: lanes whose band has ended read it; it is beyond every edge
+                sx[n] = PAD_COORD; sy[n] = PAD_COORD; sz[n] = PAD_COORD;
+                if (WEIGHTED) sw[n] = 0.0;
+                if (MERGED) sk[n] = 0;
             }
+            if (WEIGHTED && !c1.w)
+                for (int e = lane; e < n; e += 64) sw[e] = 1.0;
             __syncthreads();
             // band of every lane object inside this stage: [lo, hi) = entries with klo <= key <= khi
             int lo[R], hi[R];
             const int top = 1 << (31 - __builtin_clz(n));  // largest power of two <= n
 #pragma unroll
             for (int r = 0; r < R; ++r) lo[r] = hi[r] = 0;
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
+            for (int step = 0; step > 0; step >>= 1) {  // diagnostics: no search either
+#else
             for (int step = top; step > 0; step >>= 1) {
+#endif
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int pl = lo[r] + step, ph = hi[r] + step;
                     const double kl = skey[(pl < n ? pl : n) - 1], kh = skey[(ph < n ? ph : n) - 1];
-                    if (pl <= n && kl < klo[r]) lo[r] = pl;    // entries [0, lo) have key <  klo
-                    if (ph <= n && kh <= khi[r]) hi[r] = ph;   // entries [0, hi) have key <= khi
+                    lo[r] = (pl <= n && kl < klo[r]) ? pl : lo[r];    // entries [0, lo) have key <  klo
+                    hi[r] = (ph <= n && kh <= khi[r]) ? ph : hi[r];   // entries [0, hi) have key <= khi
                 }
             }
             int len = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (!ok[r]) hi[r] = lo[r];
+                if (!ok[r]) lo[r] = hi[r] = n;  // lanes without an object walk the sentinel
                 len = max(len, hi[r] - lo[r]);
-                nev += (unsigned long long)(hi[r] - lo[r]);
+                nev += (unsigned int)(hi[r] - lo[r]);
             }
-            for (int s = 0; __builtin_amdgcn_ballot_w64(s < len) != 0ull; ++s) {
+            for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1
+            const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
+#else
+            const int steps = __builtin_amdgcn_readfirstlane(len);  // the longest band of the wave: uniform trip count
+#endif
+
+            // Walk the bands, one entry per lane object and trip. A lane whose band has ended moves on through the window
+            // (entries beyond the band have |du| > r_win, hence s > every upper edge: they fail the predicate by
+            // themselves) and parks on the sentinel. Occupancy, not a software pipeline inside the wave, covers the LDS
+            // latency of a trip (the pipeline would cost the registers that occupancy needs).
+            unsigned cur[R];  // LDS address of the next entry's x; y, z and the bin id follow at fixed distances
+            const unsigned last = a_sx + ((unsigned)n << 3);
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = a_sx + ((unsigned)lo[r] << 3);
+            for (int s = 0; s < steps; ++s) {
+                double bx[R], by[R], bz[R], bw[R];
+                int kb[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int idx = lo[r] + s;
-                    const bool act = idx < hi[r];
-                    const int ic = act ? idx : 0;
-                    const double bx = sx[ic], by = sy[ic], bz = sz[ic];
-                    const int kb = MERGED ? sk[ic] : 0;
-                    const double dx = ax[r] - bx;
-                    const double dy = ay[r] - by;
-                    const double dz = az[r] - bz;
+                    const unsigned a8 = cur[r] < last ? cur[r] : last;
+                    cur[r] += 8;
+                    bx[r] = lds_f64(a8);
+                    by[r] = lds_f64(a8 + (LDS_Y - LDS_X));
+                    bz[r] = lds_f64(a8 + (LDS_Z - LDS_X));
+                    bw[r] = WEIGHTED ? lds_f64(a8 - a_sx + a_sw) : 1.0;
+                    kb[r] = MERGED ? lds_i32(((a8 - a_sx) >> 1) + a_sx + (LDS_K - LDS_X)) : 0;
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const double dx = ax[r] - bx[r];
+                    const double dy = ay[r] - by[r];
+                    const double dz = az[r] - bz[r];
                     const double xx = dx * dx;
                     const double yy = dy * dy;
                     const double zz = dz * dz;
-                    const double sxy = xx + yy;
-                    const double sd = sxy + zz;
-                    const double *tk = thr + kb * n_edges;
+                    const double sxy2 = xx + yy;
+                    const double sd = sxy2 + zz;
+                    const double *tk = thr + kb[r] * n_edges;  // edge table of the entry's bin
                     const double e_lo = (!MERGED || UNI) ? t_lo : tk[0];
                     const double e_hi = (!MERGED || UNI) ? t_hi : tk[n_edges - 1];
-                    const bool in = act && sd > e_lo && sd <= e_hi;
+                    const bool in = sd > e_lo && sd <= e_hi;
                     if (NF1 && !MERGED && !WEIGHTED) {
                         cnt1 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(in));
+                    } else if (NF1 && !WEIGHTED) {
+                        // branch-free: a miss adds to the lane's own dummy cell (under a branch the compiler can no longer
+                        // count the LDS operations in flight)
+                        const unsigned cell = in ? ((unsigned)kb[r] << ksh) + a_cell : a_dummy;
+                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, 1u, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (in) {
-                        int hslot = kb * nf;
+                        int slot = kb[r] * nf;
                         if (!NF1) {
                             int c = 0;
-                            for (int e = 0; e < n_edges; ++e) c += (sd > tk[e]) ? 1 : 0;
-                            hslot += c - 1;  // t[c-1] < s <= t[c], c >= 1 because s > t[0]
+                            for (int q = 0; q < n_edges; ++q) c += (sd > tk[q]) ? 1 : 0;
+                            slot += c - 1;  // t[c-1] < s <= t[c], c >= 1 because s > t[0]
                         }
                         // wave-private LDS histogram: integer adds are exact; float64 adds of ONE instruction that
                         // hit the same slot are serialised by the LDS in a fixed lane order -> reproducible sums
-                        if (WEIGHTED) atomicAdd(reinterpret_cast<double *>(hist) + hslot, aw[r] * sw[ic]);
-                        else atomicAdd(reinterpret_cast<unsigned int *>(hist) + hslot, 1u);
+                        const unsigned cell = ((unsigned)slot << ksh) + a_cell;
+                        if constexpr (WEIGHTED)
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * bw[r],
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, 1u,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -1019,7 +1094,7 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
         flush();
         // evaluated band entries of the item -> one of EVAL_SLOTS counters (statistics)
         for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
-        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], nev);
+        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
     }
 }
 
@@ -1408,7 +1483,7 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     const int saxis = (o + 2) % 3;  // z -> y, y -> x, x -> z
     std::vector<int64_t> h_poff((size_t)n_groups + 1);
     for (int g = 0; g <= n_groups; ++g) h_poff[(size_t)g] = seg ? c->h_off[(size_t)g] : c->h_off[(size_t)g * c->nb];
-    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double) + 16;  // + 16: the band kernel's 16-byte loads may touch the bytes behind the last element
     uint32_t *perm = nullptr, *perm2 = nullptr, *run = nullptr, *run_sorted = nullptr;
     int32_t *gidx = nullptr, *lohi = nullptr;
     int64_t *poff = nullptr;
@@ -1470,7 +1545,7 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.y), col);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
     if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
-    if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), n1 * sizeof(int32_t));
+    if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), n1 * sizeof(int32_t) + 16);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
     if (e != hipSuccess) return bail(e, "strip layout");
     hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->x, c->y, c->z, c->w, L.x, L.y, L.z, L.w);
@@ -1668,7 +1743,7 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
     // Library-private order: the columns go to the device as they are and are ordered there (rocPRIM radix sorts,
     // yawhip_sort.hip): ascending along the sort axis inside every (patch, bin) segment. The strip layouts are derived
     // from this resident copy (build_strip_layout), the one of the catalogue's own sort axis right away.
-    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    const size_t col = (size_t)std::max<int64_t>(n, 1) * sizeof(double) + 16;  // + 16: see build_strip_layout
     double *rx = nullptr, *ry = nullptr, *rz = nullptr, *rw = nullptr;  // raw columns (temporary)
     uint32_t *perm = nullptr;
     int64_t *poff = nullptr;
@@ -1898,13 +1973,14 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
                               (size_t)lean_bins * nf * (weighted_any ? 8 * (MWG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
                               (size_t)MWG * sizeof(unsigned int) + 16;
-    const size_t lds_band = (size_t)BCAP * sizeof(double) * (weighted_any ? 4 : 3) + (size_t)lean_bins * n_edges * sizeof(double) +
-                            (size_t)lean_bins * nf * (weighted_any ? 8 : 4) + (merged ? (size_t)BCAP * sizeof(int) : 0) + 16;
-    if (lean && (band ? lds_band : lds_merged) > (size_t)ctx->lds_limit)
-        return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band : lds_merged);
     bool uniform_t = true;  // every bin has the same threshold row (angular scales)
     for (int k = 1; k < n_bins && uniform_t; ++k)
         uniform_t = memcmp(t, t + (size_t)k * n_edges, sizeof(double) * n_edges) == 0;
+    const int hp_shift = lean_bins * nf <= 32 ? 2 : 0;  // few histogram slots: four copies, lanes spread over them
+    const bool band_thr = nf != 1 || (merged && !uniform_t);
+    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift);
+    if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
+        return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
@@ -2128,7 +2204,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
-                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_rwin.ptr, flush_mask, ctx->d_counts.ptr,             \
+                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_rwin.ptr, flush_mask, hp_shift, ctx->d_counts.ptr,   \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
 #define YAW_LAUNCH_BAND_R(WW, NN, MM, UU)                                                                             \
