@@ -123,15 +123,19 @@ __host__ __device__ inline int item_orient(const Item &it) { return (int)((unsig
 // Orientation o = the sort axis u of the layout (0 = x, 1 = y, 2 = z); strips are cut along v = (o + 2) % 3 and the
 // third axis w = (o + 1) % 3 is the one the projection drops: a job uses the orientation whose w points towards its
 // two patches, where the (u, v) projection of the sphere is least compressed.
+// (pointers carry the global address space: loaded from a table the compiler could not tell, and would use flat loads)
+typedef const __attribute__((address_space(1))) double *gf64p;
+typedef const __attribute__((address_space(1))) int32_t *gi32p;
+typedef const __attribute__((address_space(1))) int64_t *gi64p;
 struct DevTab {
-    const double *x, *y, *z, *w;          // columns; w may be null
-    const int32_t *k;                     // bin id per object (merged cross-correlation layouts), else null
-    const int64_t *off;                   // run offsets [V+1] (strip layouts) or segment offsets
-    const int64_t *vbase, *slo, *tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
-    int32_t axis;                         // sort axis inside a run / segment
+    gf64p x, y, z, w;          // columns; w may be null
+    gi32p k;                   // bin id per object (merged cross-correlation layouts), else null
+    gi64p off;                 // run offsets [V+1] (strip layouts) or segment offsets
+    gi64p vbase, slo, tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
+    int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
-__device__ __forceinline__ const double *tab_key(const DevTab &t) { return t.axis == 0 ? t.x : (t.axis == 1 ? t.y : t.z); }
+__device__ __forceinline__ gf64p tab_key(const DevTab &t) { return t.axis == 0 ? t.x : (t.axis == 1 ? t.y : t.z); }
 
 // ------------------------------------------------------------------------------------------------
 // Item builder: one thread per potential item (slot, lane tile).
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const int job = lo, p = jobs[2 * job], q = jobs[2 * job + 1];
         const int o = job_runs[3 * job + 2];  // orientation of the job: which pair of layouts it runs on
         const DevTab &c1 = tabs[o], &c2 = tabs[3 + o];
-        const double *key1 = tab_key(c1), *key2 = tab_key(c2);
+        const gf64p key1 = tab_key(c1), key2 = tab_key(c2);
         // potential items of a job, in this order: run of patch q, neighbour offset d, lane tile of the run.
         // Consecutive items then stream adjacent windows of one c1 run and the three visits of a lane
         // tile stay close in time (both sides hit in L2).
@@ -546,8 +550,9 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
     const Item it = items[ticket];
     const int o = item_orient(it), islot = item_slot(it);
     const DevTab T1 = tabs[o], T2 = tabs[3 + o];
-    const MergedView c1{T1.x, T1.y, T1.z, T1.w, T1.k};
-    const CatView c2{T2.x, T2.y, T2.z, T2.w, T2.off, 1, tab_key(T2), T2.axis};
+    const MergedView c1{(const double *)T1.x, (const double *)T1.y, (const double *)T1.z, (const double *)T1.w, (const int32_t *)T1.k};
+    const CatView c2{(const double *)T2.x, (const double *)T2.y, (const double *)T2.z, (const double *)T2.w, (const int64_t *)T2.off, 1,
+                     (const double *)tab_key(T2), T2.axis};
     const int kfix = MERGED ? 0 : islot % n_bins;  // the item's bin (ordinary items)
     const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
     const int nslots = nkb * nf;
@@ -863,11 +868,12 @@ __host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr,
            (band_small_hist(weighted, nslots, hp) ? 0 : (size_t)nslots * hp * (weighted ? 8 : 4)) + 16;
 }
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
+__device__ __forceinline__ __attribute__((address_space(3))) void *lds_ptr(unsigned addr) { return (__attribute__((address_space(3))) void *)(size_t)addr; }
 __device__ __forceinline__ double lds_f64(unsigned addr) { return *(const __attribute__((address_space(3))) double *)(size_t)addr; }
 __device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribute__((address_space(3))) int *)(size_t)addr; }
 
 template <int R, bool WEIGHTED, bool NF1, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
                                                    unsigned long long *__restrict__ out_counts,
@@ -914,34 +920,39 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
         const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
         const int64_t b0 = it.b0, nb_total = it.nb;
-        const int64_t a_end = it.a0 + it.na;
 
         __syncthreads();  // the previous item of this workgroup has left the LDS
-        // stage of the window -> LDS, 16 bytes per lane and instruction; lanes past the stage stay out of it
+        // stage of the window -> LDS, 16 bytes per lane and instruction; lanes past the stage stay out of it.
+        // (wave-uniform 64-bit bases + 32-bit lane offsets: the loads take their base from scalar registers)
         auto stage_in = [&](int64_t first, int n) {
+            const gf64p gx = c1.x + b0 + first, gy = c1.y + b0 + first, gz = c1.z + b0 + first;
 #pragma unroll
             for (int c = 0; c < (BCAP + 127) / 128; ++c) {
-                const int e = c * 128 + 2 * lane;
-                if (e < n) {
-                    __builtin_amdgcn_global_load_lds(c1.x + b0 + first + e, sx + c * 128, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(c1.y + b0 + first + e, sy + c * 128, 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(c1.z + b0 + first + e, sz + c * 128, 16, 0, 0);
-                    if (WEIGHTED && c1.w) __builtin_amdgcn_global_load_lds(c1.w + b0 + first + e, sw + c * 128, 16, 0, 0);
+                const unsigned e = (unsigned)(c * 128 + 2 * lane);
+                if (e < (unsigned)n) {
+                    __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_sx + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_sx + (LDS_Y - LDS_X) + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_sx + (LDS_Z - LDS_X) + c * 1024), 16, 0, 0);
+                    if (WEIGHTED && c1.w) __builtin_amdgcn_global_load_lds(c1.w + b0 + first + e, lds_ptr(a_sw + c * 1024), 16, 0, 0);
                 }
             }
-            if (MERGED && 4 * lane < n) __builtin_amdgcn_global_load_lds(c1.k + b0 + first + 4 * lane, sk, 16, 0, 0);
+            if (MERGED && (unsigned)(4 * lane) < (unsigned)n)
+                __builtin_amdgcn_global_load_lds(c1.k + b0 + first + (unsigned)(4 * lane), lds_ptr(a_sx + (LDS_K - LDS_X)), 16, 0, 0);
         };
         stage_in(0, (int)(nb_total < BCAP ? nb_total : BCAP));
         // lane objects and thresholds while the stage is in flight
         double ax[R], ay[R], az[R], aw[R];
         bool ok[R];
+        {
+            const gf64p px = c2.x + it.a0, py = c2.y + it.a0, pz = c2.z + it.a0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int64_t i = it.a0 + (int64_t)r * 64 + lane;
-            ok[r] = i < a_end;
-            const int64_t ic = ok[r] ? i : it.a0;
-            ax[r] = c2.x[ic]; ay[r] = c2.y[ic]; az[r] = c2.z[ic];
-            aw[r] = (WEIGHTED && c2.w) ? c2.w[ic] : 1.0;
+            for (int r = 0; r < R; ++r) {
+                const unsigned i = (unsigned)(r * 64 + lane);
+                ok[r] = i < (unsigned)it.na;
+                const unsigned ic = ok[r] ? i : 0u;
+                ax[r] = px[ic]; ay[r] = py[ic]; az[r] = pz[ic];
+                aw[r] = (WEIGHTED && c2.w) ? (c2.w + it.a0)[ic] : 1.0;
+            }
         }
         double t_lo = 0.0, t_hi = 0.0;  // edges of the item's bin (or of every bin) in registers
         if (!MERGED || UNI) {
@@ -1145,6 +1156,11 @@ __global__ void k_reduce_slots(const double *__restrict__ chunk_sums, const int6
 __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, double *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (double)in[i];
+}
+
+inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
+                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, int axis) {
+    return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles, axis, 0};
 }
 
 template <typename T>
@@ -2089,12 +2105,12 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         for (int o = 0; o < 3; ++o) {
             if (!L1[o]) continue;
             const StripLayout &a = *L1[o], &b = *L2[o];
-            h_tabs[o] = DevTab{a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx], o, 0};
-            h_tabs[3 + o] = DevTab{b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx], o, 0};
+            h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx], o);
+            h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx], o);
         }
     } else {
-        h_tabs[0] = DevTab{c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, c1->axis, 0};
-        h_tabs[3] = DevTab{c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, c2->axis, 0};
+        h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, c1->axis);
+        h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, c2->axis);
     }
     HIP_TRY(ctx->d_tabs.reserve(6));
     HIP_TRY(hipMemcpyAsync(ctx->d_tabs.ptr, h_tabs, sizeof h_tabs, hipMemcpyHostToDevice, ctx->stream));
