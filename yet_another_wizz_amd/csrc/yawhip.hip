@@ -287,19 +287,25 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
             const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
             if (b1 > b0) {
                 const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
-                l = b0; h = b1;  // first index with key >= wlo
-                while (l < h) {
-                    const int64_t m = (l + h) >> 1;
-                    if (key1[m] < wlo) l = m + 1; else h = m;
+                // four potential items in five pair a lane tile with a run that lies entirely before or behind its
+                // window (neighbouring patches share a boundary only): two loads settle those
+                if (key1[b1 - 1] < wlo || key1[b0] > whi) {
+                    b1 = b0;
+                } else {
+                    l = b0; h = b1;  // first index with key >= wlo
+                    while (l < h) {
+                        const int64_t m = (l + h) >> 1;
+                        if (key1[m] < wlo) l = m + 1; else h = m;
+                    }
+                    const int64_t first = l;
+                    h = b1;  // first index with key > whi
+                    while (l < h) {
+                        const int64_t m = (l + h) >> 1;
+                        if (key1[m] <= whi) l = m + 1; else h = m;
+                    }
+                    b0 = first;
+                    b1 = l;
                 }
-                const int64_t first = l;
-                h = b1;  // first index with key > whi
-                while (l < h) {
-                    const int64_t m = (l + h) >> 1;
-                    if (key1[m] <= whi) l = m + 1; else h = m;
-                }
-                b0 = first;
-                b1 = l;
             }
             keep = b1 > b0;
             it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0);
@@ -1184,7 +1190,36 @@ struct DevBuf {  // grow-only device workspace
     }
 };
 
+// Small per-call tables travel in ONE host-to-device copy from a pinned staging buffer, and the results (counters, counts,
+// sums) come back in ONE copy into pinned memory: a dozen pageable copies of a few hundred bytes each cost more host
+// time than the kernels of a small call take.
+struct Arena {
+    unsigned char *h = nullptr, *d = nullptr;  // pinned host image and device buffer of the same size
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        release();
+        const size_t want = n + n / 4 + 4096;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d), want);
+        if (e == hipSuccess) cap = want; else release();
+        return e;
+    }
+    void release() {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr;
+        cap = 0;
+    }
+};
+inline size_t align16(size_t n) { return (n + 15) & ~(size_t)15; }
+
 }  // namespace
+
+template <typename T>
+struct View {  // typed window into one of the context's arenas, set by every yawhip_count_pairs call
+    T *ptr = nullptr;
+};
 
 struct yawhip_ctx {
     int device = 0;
@@ -1200,21 +1235,22 @@ struct yawhip_ctx {
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
     int n_cu = 256;
-    DevBuf<int32_t> d_jobs;
-    DevBuf<int64_t> d_prefix;
-    DevBuf<double> d_t;
-    DevBuf<float> d_dthr;
-    DevBuf<double> d_rwin;
+    View<int32_t> d_jobs;
+    View<int64_t> d_prefix;
+    View<double> d_t;
+    View<float> d_dthr;
+    View<double> d_rwin;
     DevBuf<Item> d_items;
-    DevBuf<unsigned long long> d_ctr;   // [0] kept items, [1] evaluated pairs
-    DevBuf<unsigned long long> d_counts;
-    DevBuf<double> d_sums;
+    View<unsigned long long> d_ctr;
+    View<unsigned long long> d_counts;
+    View<double> d_sums;
     DevBuf<double> d_partials;
     DevBuf<double> d_chunk_sums;
     DevBuf<int64_t> d_cprefix;
     DevBuf<unsigned char> d_kept;   // weighted runs: 1 for potential items the builder kept
     DevBuf<unsigned long long> d_jobwork;
-    DevBuf<DevTab> d_tabs;
+    Arena in, out;  // per-call tables (host -> device) and results (device -> host)
+    View<DevTab> d_tabs;
     yawsort::Workspace sort_ws;  // upload-side sorts
     int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
@@ -1651,21 +1687,14 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     if (!ctx) return YAWHIP_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->d_jobs.release();
-    ctx->d_prefix.release();
-    ctx->d_t.release();
-    ctx->d_dthr.release();
-    ctx->d_rwin.release();
     ctx->d_items.release();
-    ctx->d_ctr.release();
-    ctx->d_counts.release();
-    ctx->d_sums.release();
     ctx->d_partials.release();
     ctx->d_chunk_sums.release();
     ctx->d_cprefix.release();
     ctx->d_kept.release();
     ctx->d_jobwork.release();
-    ctx->d_tabs.release();
+    ctx->in.release();
+    ctx->out.release();
     ctx->sort_ws.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -2069,10 +2098,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const bool run_weighted = weighted && want_sums;
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
-    HIP_TRY(ctx->d_jobs.reserve((size_t)5 * std::max<int64_t>(n_jobs, n_sjobs)));
-    HIP_TRY(ctx->d_prefix.reserve((size_t)n_pslots + 1));
-    HIP_TRY(ctx->d_t.reserve((size_t)n_bins * n_edges));
-    HIP_TRY(ctx->d_dthr.reserve((size_t)3 * n_bins));
     std::vector<float> dthr((size_t)3 * n_bins);  // per bin: pre-filter threshold, certain-band lower / upper bound
     auto round_down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -4.0f); return f; };
     for (int k = 0; k < n_bins; ++k) {
@@ -2082,22 +2107,10 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         dthr[(size_t)3 * k + 1] = 0.f;  // reserved
         dthr[(size_t)3 * k + 2] = 0.f;
     }
-    HIP_TRY(ctx->d_counts.reserve((size_t)n_out));
-    HIP_TRY(ctx->d_sums.reserve((size_t)n_out));
+    std::vector<double> rwin((size_t)n_bins);
+    for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
+    if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
-    if (strip_items) {
-        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, sjobs.data(), sizeof(int32_t) * 2 * n_sjobs, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, job_runs.data(), sizeof(int32_t) * 3 * n_sjobs,
-                               hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        HIP_TRY(hipMemcpyAsync(ctx->d_jobs.ptr, jobs, sizeof(int32_t) * 2 * n_jobs, hipMemcpyHostToDevice, ctx->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(ctx->d_prefix.ptr, prefix.data(), sizeof(int64_t) * (n_pslots + 1), hipMemcpyHostToDevice,
-                           ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_t.ptr, t, sizeof(double) * n_bins * n_edges, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(ctx->d_dthr.ptr, dthr.data(), sizeof(float) * 3 * n_bins, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_counts.ptr, 0, sizeof(unsigned long long) * n_out, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_sums.ptr, 0, sizeof(double) * n_out, ctx->stream));
     // layout table of the call: [o] = c1, [3 + o] = c2 for orientation o (plain layouts: entries 0 and 3)
     DevTab h_tabs[6];
     memset(h_tabs, 0, sizeof h_tabs);
@@ -2112,27 +2125,56 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, c1->axis);
         h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, c2->axis);
     }
-    HIP_TRY(ctx->d_tabs.reserve(6));
-    HIP_TRY(hipMemcpyAsync(ctx->d_tabs.ptr, h_tabs, sizeof h_tabs, hipMemcpyHostToDevice, ctx->stream));
+    // the tables of the call, packed into the pinned staging buffer and sent with one copy
+    const size_t n_jobtab = strip_items ? (size_t)5 * n_sjobs : (size_t)2 * n_jobs;  // (p, q) pairs, then (first run, runs, orientation)
+    size_t off_in = 0;
+    auto take = [&](size_t bytes) { const size_t o = off_in; off_in = align16(off_in + bytes); return o; };
+    const size_t o_jobs = take(n_jobtab * sizeof(int32_t));
+    const size_t o_prefix = take(((size_t)n_pslots + 1) * sizeof(int64_t));
+    const size_t o_t = take((size_t)n_bins * n_edges * sizeof(double));
+    const size_t o_dthr = take((size_t)3 * n_bins * sizeof(float));
+    const size_t o_rwin = take((size_t)n_bins * sizeof(double));
+    const size_t o_tabs = take(sizeof h_tabs);
+    HIP_TRY(ctx->in.reserve(off_in));
+    if (strip_items) {
+        memcpy(ctx->in.h + o_jobs, sjobs.data(), sizeof(int32_t) * 2 * n_sjobs);
+        memcpy(ctx->in.h + o_jobs + sizeof(int32_t) * 2 * n_sjobs, job_runs.data(), sizeof(int32_t) * 3 * n_sjobs);
+    } else {
+        memcpy(ctx->in.h + o_jobs, jobs, sizeof(int32_t) * 2 * n_jobs);
+    }
+    memcpy(ctx->in.h + o_prefix, prefix.data(), sizeof(int64_t) * ((size_t)n_pslots + 1));
+    memcpy(ctx->in.h + o_t, t, sizeof(double) * n_bins * n_edges);
+    memcpy(ctx->in.h + o_dthr, dthr.data(), sizeof(float) * 3 * n_bins);
+    memcpy(ctx->in.h + o_rwin, rwin.data(), sizeof(double) * n_bins);
+    memcpy(ctx->in.h + o_tabs, h_tabs, sizeof h_tabs);
+    HIP_TRY(hipMemcpyAsync(ctx->in.d, ctx->in.h, off_in, hipMemcpyHostToDevice, ctx->stream));
+    ctx->d_jobs.ptr = reinterpret_cast<int32_t *>(ctx->in.d + o_jobs);
+    ctx->d_prefix.ptr = reinterpret_cast<int64_t *>(ctx->in.d + o_prefix);
+    ctx->d_t.ptr = reinterpret_cast<double *>(ctx->in.d + o_t);
+    ctx->d_dthr.ptr = reinterpret_cast<float *>(ctx->in.d + o_dthr);
+    ctx->d_rwin.ptr = reinterpret_cast<double *>(ctx->in.d + o_rwin);
+    ctx->d_tabs.ptr = reinterpret_cast<DevTab *>(ctx->in.d + o_tabs);
+    // results: [counters][counts][sums] in one device buffer, zeroed by one memset (sums are always fully written) and
+    // fetched by one copy
+    const size_t o_ctr = 0, o_counts = align16(N_CTR * sizeof(unsigned long long)),
+                 o_sums = o_counts + align16((size_t)n_out * sizeof(unsigned long long));
+    const size_t out_bytes = o_sums + align16((size_t)n_out * sizeof(double));
+    HIP_TRY(ctx->out.reserve(out_bytes));
+    ctx->d_ctr.ptr = reinterpret_cast<unsigned long long *>(ctx->out.d + o_ctr);
+    ctx->d_counts.ptr = reinterpret_cast<unsigned long long *>(ctx->out.d + o_counts);
+    ctx->d_sums.ptr = reinterpret_cast<double *>(ctx->out.d + o_sums);
+    HIP_TRY(hipMemsetAsync(ctx->out.d, 0, n_items > 0 ? o_sums : out_bytes, ctx->stream));
 
     // LDS: two stages + thresholds + histogram(s)
     const size_t lds_fixed = 2 * STAGE * (sizeof(Obj) + sizeof(ObjF)) + (size_t)((n_edges + 1) & ~1) * sizeof(double);
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
     const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
-    unsigned long long ctr[2] = {0ull, 0ull};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_pot > 0) {
         if (n_pot >= (1ll << 31))
             return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
         HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
-        HIP_TRY(ctx->d_ctr.reserve(N_CTR));
-        HIP_TRY(ctx->d_rwin.reserve((size_t)n_bins));
-        std::vector<double> rwin((size_t)n_bins);
-        for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
-        if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
-        HIP_TRY(hipMemcpyAsync(ctx->d_rwin.ptr, rwin.data(), sizeof(double) * n_bins, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->d_ctr.ptr, 0, (band ? N_CTR : 2) * sizeof(unsigned long long), ctx->stream));
         unsigned char *kept_flags = nullptr;  // weighted runs of the culling builders: which potential items write a slab
         if (run_weighted && sweep) {
             HIP_TRY(ctx->d_kept.reserve((size_t)n_pot));
@@ -2156,14 +2198,15 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         ++launches;
         // The count kernels are launched over all potential items and return at once for indices beyond the
         // number the builder kept (device counter): no host round trip between the two kernels.
-        HIP_TRY(hipMemcpyAsync(ctr, ctx->d_ctr.ptr, sizeof ctr, hipMemcpyDeviceToHost, ctx->stream));
         n_items = n_pot;
         if (strip_items && !band && n_pot > SYNC_GRID_MIN_ITEMS) {
-            // The strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
+            // SWEEP: the strip path keeps about one potential item in five; a grid over all of them spends ~0.2 ms
             // dispatching workgroups that exit at once (measured at 1.6e6 potential items, 10M x 10M), more than
             // this round trip (~0.05 ms) costs. Small calls (one GPU's share of a sharded job list) skip it.
+            // (The band kernel sizes its grid from the potential items and loops: no round trip.)
+            HIP_TRY(hipMemcpyAsync(ctx->out.h, ctx->d_ctr.ptr, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
-            n_items = (int64_t)ctr[0];
+            n_items = (int64_t)reinterpret_cast<unsigned long long *>(ctx->out.h)[0];
         }
     }
     if (ctx->job_work_out) {  // cost estimate only: evaluated pairs per job from the item list, no counting
@@ -2202,7 +2245,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         return hipGetLastError();
     };
     HIP_TRY(hipEventRecord(ctx->evc0, ctx->stream));
-    std::vector<unsigned long long> eval_ctr;
+    bool band_ran = false;
     if (n_items > 0 && lean && band) {
         // Grid from the number of POTENTIAL items (known on the host); the kernel reads the number the builder kept
         // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
@@ -2254,10 +2297,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             HIP_TRY(reduce_partials(merged ? (int64_t)n_jobs : n_slots, slab));  // slabs are reduced per output slot
             launches += 2;
         }
-        if (stats) {
-            eval_ctr.resize(N_CTR);
-            HIP_TRY(hipMemcpyAsync(eval_ctr.data(), ctx->d_ctr.ptr, sizeof(unsigned long long) * N_CTR, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        band_ran = true;
     } else if (n_items > 0 && lean) {
         auto launch_lean = [&](bool wgt) -> hipError_t {
             const int64_t max_grid = (1ll << 31) / MWG;  // at most 2^32 - 1 work-items per launch dimension
@@ -2334,11 +2374,13 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         ++launches;
     }
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    if (want_counts)
-        HIP_TRY(hipMemcpyAsync(fine_counts, ctx->d_counts.ptr, sizeof(int64_t) * n_out, hipMemcpyDeviceToHost, ctx->stream));
-    if (want_sums)
-        HIP_TRY(hipMemcpyAsync(fine_sums, ctx->d_sums.ptr, sizeof(double) * n_out, hipMemcpyDeviceToHost, ctx->stream));
+    // one copy brings back the counters and whatever was asked for, into pinned memory
+    const size_t fetch = want_sums ? out_bytes : (want_counts ? o_sums : o_counts);
+    HIP_TRY(hipMemcpyAsync(ctx->out.h, ctx->out.d, fetch, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (want_counts) memcpy(fine_counts, ctx->out.h + o_counts, sizeof(int64_t) * n_out);
+    if (want_sums) memcpy(fine_sums, ctx->out.h + o_sums, sizeof(double) * n_out);
+    const unsigned long long *ctr = reinterpret_cast<const unsigned long long *>(ctx->out.h + o_ctr);
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -2347,9 +2389,9 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->count_ms = cms;
         stats->candidate_pairs = cand;
         stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
-        if (!eval_ctr.empty()) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
+        if (band_ran) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
             unsigned long long ev = 0;
-            for (int i = 0; i < EVAL_SLOTS; ++i) ev += eval_ctr[8 + 8 * (size_t)i];
+            for (int i = 0; i < EVAL_SLOTS; ++i) ev += ctr[8 + 8 * (size_t)i];
             stats->evaluated_pairs = (int64_t)ev;
         }
         stats->algorithmic_bytes = abytes;
