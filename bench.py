@@ -90,6 +90,23 @@ def make_catalogs(args):
     return config, ref, unk
 
 
+def make_auto_catalogs(n_data, n_rand, weighted=True, patches=64, zbins=30):
+    """BASELINE config #4: data + randoms of an autocorrelation, both with redshifts (seeds 101 / 303);
+    the same recipe tools/time_reference.py feeds to the reference."""
+    import yet_another_wizz_amd as yaw
+
+    centers = yaw.AngularCoordinates(fibonacci_centers(patches))
+
+    def cat(seed, n):
+        ra, dec, rng = uniform_sky(seed, int(n))
+        z = rng.uniform(0.1, 1.0, len(ra))
+        w = rng.uniform(0.5, 1.5, len(ra)) if weighted else None
+        return yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=w, patch_centers=centers, degrees=False)
+
+    config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=zbins)
+    return config, cat(101, n_data), cat(303, n_rand)
+
+
 # ---------------------------------------------------------------------------------------------- cpu baseline
 def cpu_baseline(links, ref, unk, budget_s):
     """Time the CPU oracle (oracle/paircount_oracle.c, brute force, OpenMP over the host's cores) on a

@@ -63,6 +63,10 @@ typedef struct yawhip_stats {
                                   reduction) on the context's stream                                     */
     double total_ms;           /* host wall time of the whole call (job upload, kernels, result download)*/
     double count_ms;           /* HIP-event time of the count kernel(s) alone (ABI >= 2)                 */
+    int32_t layout_mode;       /* which device layouts the items came from (ABI >= 3): 0 = (patch, bin, u) segments,
+                                  1 = (patch, strip) runs with all bins merged (binned x unbinned), 3 = (patch, bin,
+                                  strip) runs (binned x binned, dense catalogues)                       */
+    int32_t n_orientations;    /* strip layouts: how many of the three orientations the jobs used (ABI >= 3) */
 } yawhip_stats;
 
 const char *yawhip_last_error(void);

@@ -237,7 +237,7 @@ def test_strip_spacing_rule_and_small_helpers():
         keys = rng.integers(0, num, 5000)
         assert np.array_equal(catalog._stable_argsort_small(keys, num), np.argsort(keys, kind="stable"))
     config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=5)
-    plans, t = measurements._plans_for(config)
+    plans, t, _ = measurements._plans_for(config)
     assert measurements._plans_for(config)[1] is t and t.shape == (5, 2)
     other = yaw.Configuration.create(rmin=2.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=5)
     assert measurements._plans_for(other)[1] is not t

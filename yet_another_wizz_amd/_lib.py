@@ -53,6 +53,8 @@ class _Stats(ctypes.Structure):
         ("kernel_ms", ctypes.c_double),
         ("total_ms", ctypes.c_double),
         ("count_ms", ctypes.c_double),
+        ("layout_mode", ctypes.c_int32),
+        ("n_orientations", ctypes.c_int32),
     ]
 
 
@@ -67,6 +69,8 @@ class CountStats:
     kernel_ms: float = 0.0
     total_ms: float = 0.0
     count_ms: float = 0.0
+    layout_mode: int = 0
+    n_orientations: int = 0
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -2398,6 +2398,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         stats->n_workgroups = n_pot > 0 ? (int64_t)ctr[0] : 0;
         stats->n_launches = launches;
         stats->kernel_used = kernel;
+        stats->layout_mode = mode;
+        stats->n_orientations = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     }

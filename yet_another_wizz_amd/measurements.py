@@ -62,29 +62,50 @@ def angular_plans(config):
     ]
 
 
-def combine_all(plans, fine_bej) -> np.ndarray:
-    """``AngularBinPlan.combine`` for all bins at once: fine[B, E-1, J] -> [S, B, J]. Bins whose plans share
-    the edge count, the per-scale slices and the separation weights (always the case for angular
-    units) are handled in one vectorised pass."""
-    num_bins, _, num_jobs = fine_bej.shape
-    num_scales = plans[0].num_scales
-    out = np.empty((num_scales, num_bins, num_jobs), dtype=np.float64)
-    first = plans[0]
-    uniform = all(
-        p.num_edges == first.num_edges and p._slices == first._slices
-        and (p._scale_factor is None) == (first._scale_factor is None)
-        for p in plans
-    )
-    if uniform:
-        block = fine_bej[:, : first.num_edges - 1]
-        if first._scale_factor is not None:
-            block = block * np.stack([p._scale_factor for p in plans])[:, :, np.newaxis]
-        for s, (lo, hi) in enumerate(first._slices):
-            out[s] = block[:, lo:hi].sum(axis=1)
+class CombinePlan:
+    """``AngularBinPlan.combine`` for all redshift bins of one configuration, prepared once: bins whose plans share
+    the edge count, the per-scale slices and the separation weights (always the case for angular units) are handled
+    in one vectorised pass over fine[B, E-1, J] -> [S, B, J]."""
+
+    __slots__ = ("plans", "num_scales", "uniform", "num_fine", "slices", "scale_factors", "single")
+
+    def __init__(self, plans):
+        first = plans[0]
+        self.plans = plans
+        self.num_scales = first.num_scales
+        self.uniform = all(
+            p.num_edges == first.num_edges and p._slices == first._slices
+            and (p._scale_factor is None) == (first._scale_factor is None)
+            for p in plans
+        )
+        self.num_fine = first.num_edges - 1
+        self.slices = list(first._slices)
+        self.scale_factors = None
+        if self.uniform and first._scale_factor is not None:
+            self.scale_factors = np.stack([p._scale_factor for p in plans])[:, :, np.newaxis]
+        # the common case: one scale made of the one fine bin the device counted
+        self.single = self.uniform and self.scale_factors is None and self.slices == [(0, 1)] and self.num_fine == 1
+
+    def __call__(self, fine_bej) -> np.ndarray:
+        if self.single:
+            return fine_bej[:, 0][np.newaxis]  # a view: [1, B, J]
+        num_bins, _, num_jobs = fine_bej.shape
+        out = np.empty((self.num_scales, num_bins, num_jobs), dtype=np.float64)
+        if self.uniform:
+            block = fine_bej[:, : self.num_fine]
+            if self.scale_factors is not None:
+                block = block * self.scale_factors
+            for s, (lo, hi) in enumerate(self.slices):
+                out[s] = block[:, lo:hi].sum(axis=1)
+            return out
+        for k, plan in enumerate(self.plans):
+            out[:, k] = plan.combine(fine_bej[k, : plan.num_edges - 1].T).T
         return out
-    for k, plan in enumerate(plans):
-        out[:, k] = plan.combine(fine_bej[k, : plan.num_edges - 1].T).T
-    return out
+
+
+def combine_all(plans, fine_bej) -> np.ndarray:
+    """One-off form of :class:`CombinePlan` (``PatchLinkage`` keeps the prepared object)."""
+    return CombinePlan(plans)(fine_bej)
 
 
 def threshold_table(plans) -> np.ndarray:
@@ -128,20 +149,21 @@ def best_sort_axis(center_xyz, num_records) -> int:
     return int(np.argmin(np.abs(mean)))
 
 
-_PLAN_CACHE: list = []  # (config, plans, thresholds) of the last few configurations (they are immutable)
+_PLAN_CACHE: list = []  # (config, plans, thresholds, combine) of the last few configurations (they are immutable)
 
 
 def _plans_for(config):
-    """Angular plans and threshold table of a configuration; every measurement with the same
-    configuration object (each builds its own PatchLinkage) shares them."""
-    for cfg, plans, thresholds in _PLAN_CACHE:
+    """Angular plans, threshold table and recombination plan of a configuration; every measurement with the
+    same configuration object (each builds its own PatchLinkage) shares them."""
+    for cfg, plans, thresholds, combine in _PLAN_CACHE:
         if cfg is config:
-            return plans, thresholds
+            return plans, thresholds, combine
     plans = angular_plans(config)
     thresholds = threshold_table(plans)
-    _PLAN_CACHE.append((config, plans, thresholds))
+    combine = CombinePlan(plans)
+    _PLAN_CACHE.append((config, plans, thresholds, combine))
     del _PLAN_CACHE[:-4]
-    return plans, thresholds
+    return plans, thresholds, combine
 
 
 class PatchLinkage:
@@ -158,12 +180,14 @@ class PatchLinkage:
         # derived once per linkage (the configuration is immutable): thresholds and job tables
         self._plans = None
         self._thresholds = None
+        self._combine = None
         self._job_tables: dict = {}
+        self._scatter: dict = {}
         self._partitions: dict = {}
 
     def _angular_setup(self):
         if self._plans is None:
-            self._plans, self._thresholds = _plans_for(self.config)
+            self._plans, self._thresholds, self._combine = _plans_for(self.config)
         return self._plans, self._thresholds
 
     @classmethod
@@ -275,14 +299,21 @@ class PatchLinkage:
             fine_bej = np.moveaxis(fine, 0, -1)
 
         # host epilogue, O(jobs * B * E): separation weights, per-scale recombination, halving of the doubly
-        # counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364)
-        halve = np.where(id1 == id2, 0.5, 1.0) if auto else None
+        # counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364), scatter into [B, P, P]
         num_scales = self.config.scales.num_scales
-        counts = np.zeros((num_scales, num_bins, num_patches, num_patches), dtype=np.float64)
-        per_scale = combine_all(plans, fine_bej)  # [S, B, n_jobs]
+        per_scale = self._combine(fine_bej)  # [S, B, n_jobs]
+        skey = (auto, num_patches, num_scales, num_bins)
+        if skey not in self._scatter:  # position of every (scale, bin, job) in the dense tensor and the diagonal factor
+            flat = id1.astype(np.int64) * num_patches + id2
+            full = (np.arange(num_scales * num_bins, dtype=np.int64)[:, np.newaxis] * (num_patches * num_patches)
+                    + flat[np.newaxis, :]).ravel()
+            halve = np.where(id1 == id2, 0.5, 1.0) if auto else None
+            self._scatter[skey] = (full, halve)
+        full, halve = self._scatter[skey]
         if halve is not None:
             per_scale = per_scale * halve
-        counts[:, :, id1, id2] = per_scale
+        counts = np.zeros((num_scales, num_bins, num_patches, num_patches), dtype=np.float64)
+        counts.put(full, per_scale)  # C order on both sides: [S, B, jobs] -> [S, B, i * P + j]
         scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(num_scales)]
 
         sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
