@@ -141,8 +141,13 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
  *       t[k][e] < s <= t[k][e+1],   s = ((ax-bx)^2 + (ay-by)^2) + (az-bz)^2   in float64 without FMA.
  * Outputs (either may be NULL):
  *   fine_counts  int64[n_jobs][B][E-1]  number of pairs            (bit exact)
- *   fine_sums    float64[n_jobs][B][E-1] sum of w_a * w_b, a missing weight column counts as 1.0;
- *                deterministic for a given library build and tile_r (no floating point atomics)
+ *   fine_sums    float64[n_jobs][B][E-1] sum of w_a * w_b, a missing weight column counts as 1.0.
+ *                No floating point atomics touch global memory: per-item partial sums are combined in a fixed
+ *                order. BAND and SWEEP add into a histogram that one wave owns (LDS float64 adds in program
+ *                order): bit-reproducible from run to run for a given build and tile_r. EXACT / FILTER keep
+ *                per-lane private histograms, reduced in a fixed order, while (E-1) * 2 KiB fits LDS (E-1 <= 78);
+ *                beyond that they share one LDS histogram between four waves, whose float64 adds are ordered
+ *                by the hardware: sums then agree only to rounding (1e-10 relative is what the tests ask)
  * When both catalogues are unweighted fine_sums, if requested, is the exact conversion of fine_counts.
  */
 int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,

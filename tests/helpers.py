@@ -164,3 +164,27 @@ def run_reference_example_case():
     np.testing.assert_array_almost_equal(nz.covariance, cov)
     for cat in (ref, unk, rnd):
         cat.drop_layouts()
+
+
+def run_refcache_case():
+    """Measurements taken from the cache the REFERENCE wrote (tests/golden/refcache: data.bin / meta.yml /
+    patch_ids.bin, patch.py:164-178), against what the reference itself measured from that cache
+    (refcache_counts.npz, tools/make_golden.py --refcache-counts). Weighted: 1e-10."""
+    import os
+
+    import yet_another_wizz_amd as yaw
+    from conftest import GOLDEN
+
+    exp_in = load_golden("refcache_expect.npz")
+    exp = load_golden("refcache_counts.npz")
+    frame = {c: exp_in[f"input.{c}"] for c in ("ra", "dec", "z", "w")}
+    centers = yaw.AngularCoordinates(exp_in["patch_centers"])
+    kw = dict(ra_name="ra", dec_name="dec", weight_name="w", patch_centers=centers)
+    config = yaw.Configuration.create(rmin=0.5, rmax=8.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=4)
+    ref = yaw.Catalog(os.path.join(GOLDEN, "refcache"))
+    unk = yaw.Catalog.from_dataframe(None, frame, **kw)
+    rnd = yaw.Catalog.from_dataframe(None, frame, **kw)
+    rnz = yaw.Catalog.from_dataframe(None, frame, redshift_name="z", **kw)
+    check_corrfuncs("cross", yaw.crosscorrelate(config, ref, unk, unk_rand=rnd), exp, exact=lambda k: False)
+    check_corrfuncs("auto", yaw.autocorrelate(config, ref, rnz, count_rr=True), exp, exact=lambda k: False)
+    assert exp["cross.s0.dd.counts"].sum() > 0 and exp["auto.s0.rr.counts"].sum() > 0

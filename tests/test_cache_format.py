@@ -79,6 +79,13 @@ def test_cache_catalog_runs_through_the_driver(monkeypatch):
     np.testing.assert_allclose(a.dr.sum_weights.sum_weights1, b.dr.sum_weights.sum_weights1, rtol=1e-13)
 
 
+def test_reference_cache_measurements_match_the_reference(monkeypatch):
+    """Host logic (oracle standing in for the device): counts measured from the reference-written cache equal what
+    the reference measured from it. The device version is tests/test_gpu_api_parity.py::test_reference_cache_on_gpu."""
+    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.run_refcache_case()
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference sources only exist in the build container")
 def test_reference_reads_our_cache(tmp_path):
     """Other direction, build container only: the reference restores a cache written here."""

@@ -22,6 +22,15 @@ def test_reference_end_to_end_known_answer_on_gpu():
     helpers.run_reference_example_case()
 
 
+def test_reference_cache_on_gpu():
+    """A cache the reference wrote (data.bin / meta.yml / patch_ids.bin) -> Catalog(path) -> crosscorrelate and
+    autocorrelate on the HIP path, against the reference's own measurements from that cache."""
+    from yet_another_wizz_amd import engine
+
+    helpers.run_refcache_case()
+    assert engine.get_context() is not None
+
+
 def test_native_library_is_the_one_running():
     from yet_another_wizz_amd import _lib
 

@@ -527,3 +527,157 @@ def test_segment_strip_layout_path(ctx, weights):
         ctx.set_option("seg_strips", 1)
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("tile_r", 0)
+
+
+def _tangent_partners(rng, a, ang, direction):
+    """Points at angular distance ``ang`` from the unit vectors ``a`` along the tangent ``direction`` (projected)."""
+    v = direction - (direction * a).sum(1, keepdims=True) * a
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    b = a * np.cos(ang)[:, None] + v * np.sin(ang)[:, None]
+    return b / np.linalg.norm(b, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("kernel", ["band", "sweep"])
+@pytest.mark.parametrize("layout", ["merged", "segments"])
+@pytest.mark.parametrize("micro", [None, 2500, 1000])
+def test_borderline_pairs_on_the_strip_paths(ctx, kernel, layout, micro):
+    """The production paths -- binned x unbinned on the merged (patch, strip) runs, binned x binned on the
+    (patch, bin, strip) runs -- with engineered partners at theta_edge(k) (1 +- delta) of the object's OWN redshift bin
+    (per-bin scales), displaced along the sort axis (they sit at the edge u +- r_win of the window and of the per-object
+    band), along the strip axis (they sit in the neighbouring strips, up to ``reach`` grid cells away) and across the
+    patch boundary. Footprint around (1, 0, 0): the library sorts along z and cuts strips along y there. Bit parity
+    with the oracle, for the default grid (one cell > theta_max) and for finer grids (reach 2 and 4)."""
+    # theta_max = 8 arcmin * 1.7 -> chord 3.96e-3: grid 5e-3 (default) reach 1, 2.5e-3 reach 2, 1e-3 reach 4
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(97 + (micro or 0))
+    B, P, n = 3, 2, 6000
+    theta0 = 8.0 * np.pi / 10800
+    thetas = theta0 * (1.0 + 0.35 * np.arange(B))                       # theta_max of bin k
+    t_rows, edges = [], []
+    for k in range(B):
+        lim = oracle.parse_ang_limits([0.1 * thetas[k]], [thetas[k]])
+        ab = oracle.ang_bins_for(lim, None, None)
+        edges.append(ab)
+        t_rows.append(oracle.thresholds_for(ab))
+    t = np.stack(t_rows)
+    # c1 objects p: a small box around ra = 0, dec = 0, redshift bin k
+    ra = rng.uniform(-0.01, 0.01, n)
+    dec = rng.uniform(-0.01, 0.01, n)
+    p = np.column_stack(oracle.to_3d(ra % (2 * np.pi), dec))
+    kbin = rng.integers(0, B, n)
+    z1 = 0.1 + (kbin + rng.uniform(0.05, 0.95, n)) * (0.8 / B)
+    which_edge = rng.integers(0, 2, n)                                     # inner or outer edge of the bin's annulus
+    edge = np.array([edges[k][w] for k, w in zip(kbin, which_edge)])
+    delta = rng.choice([0.0, 1e-16, -1e-16, 3e-16, -3e-16, 1e-14, -1e-14, 1e-12, -1e-12, 1e-9, -1e-9, 1e-6, -1e-6], n)
+    ang = edge * (1.0 + delta)
+    north, east = np.array([0.0, 0.0, 1.0]), np.array([0.0, 1.0, 0.0])      # +dec = sort axis z, +ra = strip axis y
+    style = rng.integers(0, 4, n)
+    direction = np.where((style == 0)[:, None], north, np.where((style == 1)[:, None], -north,
+                         np.where((style == 2)[:, None], east, -east))) * np.ones((n, 3))
+    direction = direction + (rng.random(n) < 0.3)[:, None] * rng.normal(size=(n, 3)) * 0.3  # some oblique ones
+    q = _tangent_partners(rng, p, ang, direction)
+    ra2, dec2 = np.arctan2(q[:, 1], q[:, 0]), np.arcsin(np.clip(q[:, 2], -1, 1))
+    z2 = z1.copy()                                                          # partner in the same redshift bin (segments)
+    patch1 = (dec > 0).astype(int)                                          # patch boundary along dec = 0: pairs straddle it
+    patch2 = (dec2 > 0).astype(int)
+    zedges = np.linspace(0.1, 0.9, B + 1)
+    c1 = oracle.sort_catalog(ra % (2 * np.pi), dec, z1, None, patch1, P, zedges, "right")
+    c2 = oracle.sort_catalog(ra2 % (2 * np.pi), dec2, z2, None, patch2, P, zedges if layout == "segments" else None, "right")
+    jobs = np.array([(a, b) for a in range(P) for b in range(P)], dtype=np.int32)
+    exp, _ = oracle.count_jobs(c1, c2, jobs, t)
+    assert exp.sum() > n // 4 and (exp[1] + exp[2]).sum() > 50           # engineered pairs dominate; many cross the patch boundary
+    try:
+        if micro is not None:
+            ctx.set_option("strip_width_micro", micro)
+        if layout == "segments":
+            ctx.set_option("seg_strips_min_run", 1)
+        for axis in (2, 0):                                               # the catalogues' own sort axis does not matter
+            d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"], sort_axis=axis)
+            d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, c2["nb"], c2["off"], sort_axis=axis)
+            for tile_r in (0, 1):
+                ctx.set_option("tile_r", tile_r)
+                counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel)
+                assert st.layout_mode == (1 if layout == "merged" else 3)
+                assert np.array_equal(counts, exp), (axis, tile_r)
+            # swapped roles (unbinned x binned: plain layout) count the same pairs
+            counts, _, _ = _lib.count_pairs(ctx, d2, d1, jobs[:, ::-1].copy(), t, kernel=kernel)
+            assert np.array_equal(counts, exp)
+    finally:
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+        ctx.set_option("seg_strips_min_run", 40)
+        ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("kernel", ["exact", "filter"])
+def test_weighted_shared_histogram_corner(ctx, kernel):
+    """Weighted brute-force counts with more fine bins than per-lane private float64 histograms fit in LDS
+    ((E - 1) * 256 * 8 B > 160 KB for E - 1 > 78): the workgroup-shared float64 histogram (LDS atomics across four
+    waves). Sums within 1e-10 of the oracle (that corner is not bit-reproducible, include/yawhip.h says so)."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(404)
+    c1 = _random_catalog(rng, 3000, 2, 2, True, dense_box=1.0)
+    c2 = _random_catalog(rng, 2500, 2, 1, True, dense_box=1.0)
+    jobs = np.array([[0, 0], [0, 1], [1, 1]], dtype=np.int32)
+    lim = oracle.parse_ang_limits(np.array([0.5]) * np.pi / 10800, np.array([40.0]) * np.pi / 10800)
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, -1.0, 95)), (2, 1))
+    assert t.shape[1] - 1 > 78
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    counts, sums, st = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+    assert np.array_equal(counts, exp_c) and exp_c.sum() > 1e5 and (exp_c > 0).sum() > 0.5 * exp_c.size
+    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+    for k2 in ("band", "sweep"):  # the strip paths hold the same histogram per wave
+        counts, sums, _ = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), jobs, t, kernel=k2, want_counts=True, want_sums=True)
+        assert np.array_equal(counts, exp_c)
+        np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+
+
+def test_counts_beyond_32_bits_per_item(ctx):
+    """More than 2^32 pairs in ONE (work item, fine bin): 4.3 M streamed objects against a tile of 1024 lane objects,
+    all inside one wide bin. The 32-bit LDS counters are moved to the 64-bit result before they wrap."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(2)
+    n1, n2 = 4_300_000, 1024
+
+    def clump(n):
+        ra = np.deg2rad(50.0 + rng.normal(0, 0.02, n)); dec = np.deg2rad(10.0 + rng.normal(0, 0.02, n))
+        return oracle.sort_catalog(ra, dec, None, None, np.zeros(n, dtype=int), 1, None, "right")
+    c1, c2 = clump(n1), clump(n2)
+    t = np.array([[0.0, 3.9]])  # every pair but coincident ones
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    ctx.set_option("tile_r", 4)
+    try:
+        for kernel in ("exact", "filter", "sweep", "band"):
+            counts, _, st = _lib.count_pairs(ctx, d1, d2, [[0, 0]], t, kernel=kernel)
+            assert counts[0, 0, 0] == n1 * n2 > 2**32, kernel
+    finally:
+        ctx.set_option("tile_r", 0)
+
+
+def test_band_kernel_flush_interval(ctx):
+    """``flush_stages_log2`` = 0 makes the band kernel move its 32-bit LDS counters to the 64-bit result after every
+    stage of a long window (the path that otherwise only runs after 2^17 stages): same counts."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(8)
+    def clump(n, nb):
+        ra = np.deg2rad(200.0 + rng.normal(0, 0.01, n)); dec = np.deg2rad(-45.0 + rng.normal(0, 0.01, n))
+        z = rng.uniform(0.1, 0.9, n)
+        return oracle.sort_catalog(ra, dec, z, None, np.zeros(n, dtype=int), 1, np.linspace(0.1, 0.9, nb + 1) if nb > 1 else None, "right")
+    c1, c2 = clump(3000, 3), clump(700, 1)
+    lim = oracle.parse_ang_limits([0.2 * np.pi / 10800], [3.0 * np.pi / 10800])
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (3, 1))
+    exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    try:
+        for log2 in (0, 1, 17):
+            ctx.set_option("flush_stages_log2", log2)
+            counts, _, _ = _lib.count_pairs(ctx, d1, d2, [[0, 0]], t, kernel="band")
+            assert np.array_equal(counts, exp), log2
+            counts, _, _ = _lib.count_pairs(ctx, d1, d1, [[0, 0]], t, kernel="band")  # per-bin items
+            assert np.array_equal(counts, oracle.count_jobs(c1, c1, [[0, 0]], t)[0]), log2
+    finally:
+        ctx.set_option("flush_stages_log2", 17)
+    assert exp.sum() > 0.3 * 3000 * 700

@@ -332,14 +332,39 @@ def make_refcache(tmp):
     print("refcache files:", sorted(os.listdir(dest)), sorted(os.listdir(os.path.join(dest, "patch_0"))))
 
 
+def make_refcache_counts(tmp):
+    """The reference's own measurements taken FROM the committed reference-written cache (tests/golden/refcache):
+    crosscorrelate (DD, DR) with the cache as the reference sample and autocorrelate (DD, DR, RR) of the cache against
+    a second copy of the frame. Only the outputs are new data; the inputs are refcache/ and refcache_expect.npz."""
+    exp = np.load(os.path.join(OUT, "refcache_expect.npz"))
+    df = pd.DataFrame({c: exp[f"input.{c}"] for c in ("ra", "dec", "z", "w")})
+    centers = AngularCoordinates(exp["patch_centers"])
+    cache = os.path.join(tmp, "refcache_copy")  # build_trees writes into the cache directory: work on a copy
+    shutil.copytree(os.path.join(OUT, "refcache"), cache)
+    ref = yaw.Catalog(cache)
+    kw = dict(ra_name="ra", dec_name="dec", weight_name="w", patch_centers=centers, overwrite=True)
+    unk = yaw.Catalog.from_dataframe(os.path.join(tmp, "rc_unk"), df, **kw)
+    rnd = yaw.Catalog.from_dataframe(os.path.join(tmp, "rc_rnd"), df, **kw)
+    rnz = yaw.Catalog.from_dataframe(os.path.join(tmp, "rc_rnz"), df, redshift_name="z", **kw)
+    config = yaw.Configuration.create(rmin=0.5, rmax=8.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=4)
+    out = {}
+    dump_counts("cross", yaw.crosscorrelate(config, ref, unk, unk_rand=rnd), out)
+    dump_counts("auto", yaw.autocorrelate(config, ref, rnz, count_rr=True), out)
+    save("refcache_counts.npz", **out)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="yawgolden_", dir="/dev/shm")
     try:
+        if "--refcache-counts" in sys.argv:  # only this group (the others are already committed)
+            make_refcache_counts(tmp)
+            return
         make_refcache(tmp)
         make_greatcircle()
         make_single_job()
         make_full(tmp)
         make_2dflens(tmp)
+        make_refcache_counts(tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

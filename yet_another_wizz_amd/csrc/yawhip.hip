@@ -61,6 +61,8 @@ constexpr int MAX_EDGES = 512;
 constexpr int SEG_STRIPS_MIN_RUN = 40;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
 constexpr int64_t SYNC_GRID_MIN_ITEMS = 400000;  // potential items from which the count grid is sized exactly (one host sync)
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
+constexpr int COUNT_FLUSH_MASK = (1 << 13) - 1;  // k_count: stages between flushes of the 32-bit LDS counters (see there)
+constexpr int MERGED_FLUSH_MASK = (1 << 16) - 1; // k_count_merged: 256 lane objects x 64 streamed objects per stage
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
 thread_local std::string g_last_error;
@@ -386,6 +388,29 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
 
     const int64_t nb_total = b1 - b0;
     const int nstages = (int)((nb_total + STAGE - 1) / STAGE);
+    // LDS histogram(s) -> result: fixed-order tree reduction of the private histograms, then 64-bit integer atomics
+    // (unweighted; the histogram is cleared and counting goes on) or the item's slab (weighted, once at the end)
+    auto flush_counts = [&]() {
+        if (PRIVATE) {
+            for (int stride = WG / 2; stride > 0; stride >>= 1) {
+                if (tid < stride)
+                    for (int j = 0; j < nf; ++j) hist[j * WG + tid] += hist[j * WG + tid + stride];
+                __syncthreads();
+            }
+        }
+        for (int j = tid; j < nf; j += WG) {
+            const HistT v = PRIVATE ? hist[j * WG] : hist[j];
+            if (WEIGHTED) partials[item * nf + j] = (double)v;
+            else if (v != HistT(0)) atomicAdd(&out_counts[(int64_t)slot * nf + j], (unsigned long long)v);
+        }
+        __syncthreads();
+        if (PRIVATE) {
+            for (int j = 0; j < nf; ++j) hist[j * WG + tid] = HistT(0);
+        } else {
+            for (int j = tid; j < nf; j += WG) hist[j] = HistT(0);
+        }
+        __syncthreads();
+    };
 
     // stage 0
     {
@@ -481,21 +506,11 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
             if (FILTER) stagef[((st + 1) & 1) * STAGE + tid] = ObjF{(float)nxt.x, (float)nxt.y, (float)nxt.z, 0.f};
         }
         __syncthreads();
+        // 32-bit counters: 256 * R lane objects (R <= 4) x 256 streamed objects per stage reach 2^32 after 2^14 stages
+        // (a c1 segment of 4.2 M objects inside one wide bin): move them to the 64-bit result before that
+        if (!WEIGHTED && (st & COUNT_FLUSH_MASK) == COUNT_FLUSH_MASK && st + 1 < nstages) flush_counts();
     }
-
-    // fixed-order tree reduction of the private histograms
-    if (PRIVATE) {
-        for (int stride = WG / 2; stride > 0; stride >>= 1) {
-            if (tid < stride)
-                for (int j = 0; j < nf; ++j) hist[j * WG + tid] += hist[j * WG + tid + stride];
-            __syncthreads();
-        }
-    }
-    for (int j = tid; j < nf; j += WG) {
-        const HistT v = PRIVATE ? hist[j * WG] : hist[j];
-        if (WEIGHTED) partials[item * nf + j] = (double)v;
-        else if (v != HistT(0)) atomicAdd(&out_counts[(int64_t)slot * nf + j], (unsigned long long)v);
-    }
+    flush_counts();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -650,6 +665,19 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
         if (f * MWG + tid < MSTAGE) stagef[f * MWG + tid] = finish(first[f]);
     __syncthreads();
 
+    auto flush_hist = [&]() {  // LDS histogram -> 64-bit result (unweighted: cleared, counting goes on) / the item's slab
+        for (int idx = tid; idx < nslots; idx += MWG) {
+            if (WEIGHTED) {
+                double v = 0.0;
+                for (int wv = 0; wv < NHIST; ++wv) v += reinterpret_cast<double *>(hist)[wv * nslots + idx];
+                partials[(int64_t)it.pot * nslots + idx] = v;
+            } else {
+                const unsigned int v = reinterpret_cast<unsigned int *>(hist)[idx];
+                if (v) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)v);
+                reinterpret_cast<unsigned int *>(hist)[idx] = 0u;
+            }
+        }
+    };
     int qn = 0;  // entries in this wave's survivor queue (wave-uniform)
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
@@ -791,18 +819,13 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
         for (int f = 0; f < NPF; ++f)
             if (have_next && f * MWG + tid < MSTAGE) stagef[(cb ^ 1) * MSTAGE + f * MWG + tid] = finish(nxt[f]);
         __syncthreads();
-    }
-
-    for (int idx = tid; idx < nslots; idx += MWG) {
-        if (WEIGHTED) {
-            double v = 0.0;
-            for (int wv = 0; wv < NHIST; ++wv) v += reinterpret_cast<double *>(hist)[wv * nslots + idx];
-            partials[(int64_t)it.pot * nslots + idx] = v;
-        } else {
-            const unsigned int v = reinterpret_cast<unsigned int *>(hist)[idx];
-            if (v) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)v);
+        if (!WEIGHTED && (st & MERGED_FLUSH_MASK) == MERGED_FLUSH_MASK && have_next) {  // 32-bit counters: see k_count
+            flush_hist();
+            __syncthreads();
         }
     }
+
+    flush_hist();
 }
 
 // The kernel proper. With one or two objects per lane the body fits 64 VGPRs without spilling, so the compiler is
