@@ -12,8 +12,8 @@
  * Conventions
  *   - plain C, no C++/torch types; every pointer is caller-owned host memory unless stated otherwise,
  *     contiguous, 8-byte aligned; the library owns all device memory behind opaque handles;
- *   - one context = one GPU = (normally) one process; calls are blocking and must not be issued
- *     concurrently on the same context;
+ *   - one context = one GPU (yawhip_ctx_create) or several GPUs of the node (yawhip_ctx_create_multi) = one
+ *     process; calls are blocking and must not be issued concurrently on the same context;
  *   - every function returns 0 on success or a negative yawhip_status; nothing throws;
  *     yawhip_last_error() returns a thread-local, human readable message for the last failure.
  */
@@ -78,6 +78,15 @@ int yawhip_device_count(int *n);
 /* Create / destroy a context on device `device_id` (creates one HIP stream). */
 int yawhip_ctx_create(int device_id, yawhip_ctx **out);
 int yawhip_ctx_destroy(yawhip_ctx *ctx);
+/* One context over several GPUs of the node (ABI >= 3; replaces the worker pool behind `max_workers` of
+ * PatchLinkage.count_pairs, src/yaw/correlation/measurements.py:344-350, src/yaw/utils/parallel.py:251-346):
+ * catalogues uploaded to it are replicated on every device, yawhip_count_pairs splits its job list over the devices
+ * (longest job first, by the work the item builder reports) and returns the complete result; options apply to all
+ * devices. A device id may be listed more than once (several streams on one GPU; used by the tests). Everything
+ * else behaves as for a single-device context; yawhip_assign_patches and yawhip_job_work use the first device. */
+int yawhip_ctx_create_multi(const int *device_ids, int n_devices, yawhip_ctx **out);
+/* Number of devices a context spans. */
+int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
 
 /* Tunables (all optional):
  *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)

@@ -7,7 +7,7 @@ from oracle import oracle
 RTOL_W = 1e-10
 
 
-def oracle_count_fine(layout1, layout2, jobs, thresholds, *, kernel=None, sort_axis=2):
+def oracle_count_fine(layout1, layout2, jobs, thresholds, *, kernel=None, sort_axis=2, max_workers=None):
     """Stand-in for yet_another_wizz_amd.engine.count_fine built on the CPU oracle: lets the CPU
     suite exercise the host driver (linkage, thresholds, recombination, sharding) without a GPU."""
     from yet_another_wizz_amd._lib import CountStats

@@ -50,3 +50,56 @@ def test_three_ranks_share_one_gpu(tmp_path):
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     results = [np.load(tmp_path / f"ok{r}.npy") for r in range(world)]
     assert all(np.array_equal(results[0], r) for r in results[1:]) and results[0].sum() > 0
+
+
+def test_multi_device_context_one_call():
+    """Several GPUs behind ONE context and ONE call (yawhip_ctx_create_multi): the drop-in route -- crosscorrelate(...,
+    max_workers=N) in a single process. Rehearsed on the one GPU of this box by listing its id three times (three
+    streams, three replicas of every catalogue): the library splits the job list, every device counts its share, the rows
+    land in place. Results equal the single-device ones bit for bit (weighted sums included: a job's rows come from one
+    device, the arithmetic per job is unchanged)."""
+    import helpers
+    import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import _lib, engine
+
+    inp, cats = helpers.full_catalogs("w")
+    config = helpers.full_config(inp, "s2", "right")
+    single = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
+    auto1 = yaw.autocorrelate(config, cats["ref"], cats["ref_rand"])
+    os.environ["YAW_AMD_DEVICES"] = "0,0,0"
+    try:
+        assert engine.default_devices() == (0, 0, 0) and engine.default_devices(2) == (0, 0)
+        ctx = engine.get_context()
+        assert ctx.devices == (0, 0, 0)
+        multi = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
+        auto3 = yaw.autocorrelate(config, cats["ref"], cats["ref_rand"])
+        two = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"], max_workers=2)
+    finally:
+        del os.environ["YAW_AMD_DEVICES"]
+    for a, b in list(zip(single, multi)) + list(zip(single, two)) + list(zip(auto1, auto3)):
+        for kind in ("dd", "dr", "rd", "rr"):
+            x, y = getattr(a, kind), getattr(b, kind)
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert np.array_equal(x.counts.counts, y.counts.counts), kind
+                assert np.array_equal(x.sum_weights.sum_weights1, y.sum_weights.sum_weights1)
+    helpers.check_corrfuncs("cross", multi, helpers.load_golden("full_w_s2_right.npz"), exact=lambda k: False)  # vs the reference
+    # the C ABI directly: job split, statistics, a failing call leaves the context usable
+    l1, l2 = cats["ref"]._active_layout, cats["unk"]._active_layout
+    c3 = _lib.Context([0, 0, 0])
+    c1 = _lib.Context(0)
+    up = lambda c, l: _lib.DeviceCatalog(c, l.x, l.y, l.z, l.w, l.num_patches, l.num_bins, l.offsets)
+    jobs = np.array([(p, q) for p in range(l1.num_patches) for q in range(l1.num_patches)], dtype=np.int32)
+    t = np.array([[1e-7, 4e-6, 3e-5]] * l1.num_bins)
+    ref_counts, ref_sums, st1 = _lib.count_pairs(c1, up(c1, l1), up(c1, l2), jobs, t, want_counts=True, want_sums=True)
+    d1, d2 = up(c3, l1), up(c3, l2)
+    for _ in range(2):  # second call: the cached plan
+        counts, sums, st3 = _lib.count_pairs(c3, d1, d2, jobs, t, want_counts=True, want_sums=True)
+        assert np.array_equal(counts, ref_counts) and np.array_equal(sums, ref_sums)
+        assert st3.candidate_pairs == st1.candidate_pairs and st3.evaluated_pairs == st1.evaluated_pairs
+    with pytest.raises(_lib.YawhipError, match="ascending"):
+        _lib.count_pairs(c3, d1, d2, jobs, t[:, ::-1].copy())
+    counts, _, _ = _lib.count_pairs(c3, d1, d2, jobs[:5], t, want_counts=True)
+    assert np.array_equal(counts, ref_counts[:5])
+    for cat in cats.values():
+        cat.drop_layouts()

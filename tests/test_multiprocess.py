@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, fail_rank=-1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     sys.path.insert(0, ROOT)
@@ -30,21 +30,37 @@ def _worker(rank, world, port, out_dir):
 
     seen = []
 
-    def counting(layout1, layout2, jobs, thresholds, *, kernel=None, sort_axis=2):
+    def counting(layout1, layout2, jobs, thresholds, *, kernel=None, sort_axis=2, max_workers=None):
         seen.append(len(jobs))
+        if rank == fail_rank:
+            raise engine._lib.YawhipError("simulated device failure")
         return helpers.oracle_count_fine(layout1, layout2, jobs, thresholds)
 
     engine.count_fine = counting
     # the device's cost estimate has a host model as its CPU stand-in
     from yet_another_wizz_amd import measurements
-    engine.job_work = lambda l1, l2, jobs, t, **kw: measurements.job_costs(l1, l2, jobs, t)
+    calls = []
+
+    def job_work(l1, l2, jobs, t, **kw):
+        calls.append(rank)
+        return measurements.job_costs(l1, l2, jobs, t)
+
+    engine.job_work = job_work
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         assert parallel.world() == (rank, world)
         inp, cats = helpers.full_catalogs("w")
         config = helpers.full_config(inp, "s2", "right")
+        if fail_rank >= 0:  # a failing rank must make every rank raise, not leave the others in the collective
+            try:
+                yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
+            except RuntimeError as err:
+                with open(os.path.join(out_dir, f"rank{rank}.err"), "w") as f:
+                    f.write(str(err))
+            return
         cfs = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
         acf = yaw.autocorrelate(config, cats["ref"], cats["ref_rand"])
+        assert (len(calls) > 0) == (rank == 0)  # the partition is derived on rank 0 only and broadcast
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), jobs_seen=np.array(seen),
                  dd=cfs[0].dd.counts.counts, rr=cfs[1].rr.counts.counts, add=acf[0].dd.counts.counts,
                  w=cfs[0].sample().data)
@@ -52,30 +68,41 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_process_sharding_matches_single_process(tmp_path, monkeypatch):
+@pytest.mark.parametrize("world", [2, 8])
+def test_process_group_sharding_matches_single_process(tmp_path, monkeypatch, world):
     import torch.multiprocessing as mp
 
     import helpers
     import yet_another_wizz_amd as yaw
     from yet_another_wizz_amd import engine
 
-    world = 2
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
     inp, cats = helpers.full_catalogs("w")
     config = helpers.full_config(inp, "s2", "right")
     cfs = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])
     acf = yaw.autocorrelate(config, cats["ref"], cats["ref_rand"])
-    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
-    for r in (r0, r1):  # every rank holds the full, identical result
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    r0 = ranks[0]
+    for r in ranks:  # every rank holds the full, identical result
         assert np.array_equal(r["dd"], cfs[0].dd.counts.counts)
         assert np.array_equal(r["rr"], cfs[1].rr.counts.counts)
         assert np.array_equal(r["add"], acf[0].dd.counts.counts)
         assert np.array_equal(r["w"], cfs[0].sample().data)
     # the jobs were really split: each rank counted a strict subset, together all of them
     n_cross = len(helpers.load_golden("full_w_s2_right.npz")["cross.job_pairs"])
-    assert r0["jobs_seen"][0] + r1["jobs_seen"][0] == n_cross
+    assert sum(int(r["jobs_seen"][0]) for r in ranks) == n_cross
     assert 0 < r0["jobs_seen"][0] < n_cross
+
+
+def test_failing_rank_raises_everywhere(tmp_path):
+    """One rank's device call fails: the flag that travels with the all-reduce makes every rank raise."""
+    import torch.multiprocessing as mp
+
+    world = 3
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), 1), nprocs=world, join=True, start_method="spawn")
+    msgs = [open(tmp_path / f"rank{r}.err").read() for r in range(world)]
+    assert all("failed on 1 of 3 ranks" in m for m in msgs)
 
 
 def test_partition_is_balanced_and_complete():

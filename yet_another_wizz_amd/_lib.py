@@ -25,6 +25,8 @@ ABI_SYMBOLS = (
     "yawhip_abi_version",
     "yawhip_device_count",
     "yawhip_ctx_create",
+    "yawhip_ctx_create_multi",
+    "yawhip_ctx_device_count",
     "yawhip_ctx_destroy",
     "yawhip_ctx_set_option",
     "yawhip_catalog_upload",
@@ -100,6 +102,8 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_abi_version.argtypes = []
     lib.yawhip_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
     lib.yawhip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+    lib.yawhip_ctx_create_multi.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]
+    lib.yawhip_ctx_device_count.argtypes = [_vp, ctypes.POINTER(ctypes.c_int)]
     lib.yawhip_ctx_destroy.argtypes = [_vp]
     lib.yawhip_ctx_set_option.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int64]
     lib.yawhip_catalog_upload.argtypes = [
@@ -148,12 +152,19 @@ def _ptr(a, typ):
 
 
 class Context:
-    """One GPU (one HIP stream). ``yawhip_ctx`` of include/yawhip.h."""
+    """One GPU (one HIP stream), or several GPUs of the node behind one handle (``device`` a sequence of ids:
+    catalogues are replicated, ``count_pairs`` splits its jobs over the devices). ``yawhip_ctx`` of include/yawhip.h."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0):
         self._h = _vp()
-        _check(load_library().yawhip_ctx_create(int(device), ctypes.byref(self._h)), "yawhip_ctx_create")
-        self.device = int(device)
+        if isinstance(device, (list, tuple)):
+            ids = (ctypes.c_int * len(device))(*[int(d) for d in device])
+            _check(load_library().yawhip_ctx_create_multi(ids, len(device), ctypes.byref(self._h)), "yawhip_ctx_create_multi")
+            self.devices = tuple(int(d) for d in device)
+        else:
+            _check(load_library().yawhip_ctx_create(int(device), ctypes.byref(self._h)), "yawhip_ctx_create")
+            self.devices = (int(device),)
+        self.device = self.devices[0]
         self.strip_micro = DEFAULT_STRIP_MICRO
 
     def set_option(self, key: str, value: int) -> None:

@@ -1274,8 +1274,14 @@ struct yawhip_ctx {
     DevBuf<unsigned long long> d_jobwork;
     Arena in, out;  // per-call tables (host -> device) and results (device -> host)
     View<DevTab> d_tabs;
+    // A context made by yawhip_ctx_create_multi owns one further context per additional device: catalogues are
+    // replicated on all of them and yawhip_count_pairs splits its job list over them.
+    std::vector<yawhip_ctx *> peers;
+    struct Plan {  // job partition of the last multi-device call (a function of its inputs only)
+        uint64_t key = 0;
+        std::vector<std::vector<int32_t>> parts;  // job indices per device
+    } plan;
     yawsort::Workspace sort_ws;  // upload-side sorts
-    int64_t *job_work_out = nullptr;  // set by yawhip_job_work: yawhip_count_pairs then stops after the item builder
 };
 
 struct StripLayout {
@@ -1318,6 +1324,7 @@ struct yawhip_catalog {
     // One layout per orientation o = sort axis u (strips along (o + 2) % 3), built when a job first needs it (the one of
     // the catalogue's own sort axis at upload): see DevTab.
     StripLayout strips[3], seg[3];
+    std::vector<yawhip_catalog *> replicas;  // copies on ctx->peers (multi-device contexts), same order
     bool has_strips = false;          // strip layouts can be built (unit vectors, n > 0)
     double strip_width = 0.0;         // grid spacing (chord units); 0 = one run per patch
     std::vector<double> h_box;        // [P][6] bounding box of every patch: min x, y, z, max x, y, z (empty patch: +4 / -4)
@@ -1708,6 +1715,8 @@ int yawhip_ctx_create(int device_id, yawhip_ctx **out) {
 
 int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     if (!ctx) return YAWHIP_OK;
+    for (yawhip_ctx *peer : ctx->peers) (void)yawhip_ctx_destroy(peer);
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->d_items.release();
@@ -1730,6 +1739,11 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
 
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_set_option: NULL argument");
+    for (yawhip_ctx *peer : ctx->peers) {  // every device of a multi-device context follows
+        const int rc = yawhip_ctx_set_option(peer, key, value);
+        if (rc != YAWHIP_OK) return rc;
+    }
+    ctx->plan.key = 0;  // options change the work per job
     if (!strcmp(key, "tile_r")) {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(YAWHIP_ERR_INVALID, "tile_r must be 0 (auto), 1, 2 or 4");
@@ -1889,12 +1903,24 @@ int yawhip_catalog_upload_axis(yawhip_ctx *ctx, int64_t n, const double *x, cons
         }
     }
     if (ctx->sort_ws.cap > ((size_t)1 << 25)) ctx->sort_ws.release();  // ~30 bytes per object: keep only small workspaces
+    for (yawhip_ctx *peer : ctx->peers) {  // multi-device context: the same catalogue on every further device
+        yawhip_catalog *rep = nullptr;
+        const int rc = yawhip_catalog_upload_axis(peer, n, x, y, z, w, n_patches, n_bins_or_1, offsets, sort_axis, &rep);
+        if (rc != YAWHIP_OK) {
+            yawhip_catalog_free(c);
+            return rc;
+        }
+        c->replicas.push_back(rep);
+    }
     *out = c;
     return YAWHIP_OK;
 }
 
 int yawhip_catalog_free(yawhip_catalog *c) {
     if (!c) return YAWHIP_OK;
+    for (yawhip_catalog *rep : c->replicas) (void)yawhip_catalog_free(rep);
+    c->replicas.clear();
+    if (c->ctx) c->ctx->plan.key = 0;  // a later catalogue may reuse the address the plan was keyed on
     if (c->ctx) (void)hipSetDevice(c->ctx->device);
     if (c->x) (void)hipFree(c->x);
     if (c->y) (void)hipFree(c->y);
@@ -1915,11 +1941,31 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes) {
     return YAWHIP_OK;
 }
 
-int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
-                       const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
-                       int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
-    const auto wall0 = std::chrono::steady_clock::now();
-    if (stats) memset(stats, 0, sizeof *stats);
+}  // extern "C"
+
+namespace {
+
+// What count_finish needs to know about a call count_enqueue has put on a context's stream.
+struct CallState {
+    std::chrono::steady_clock::time_point wall0;
+    bool pending = false;          // something was enqueued (false: nothing to count, outputs are zero)
+    int64_t n_out = 0;
+    size_t o_ctr = 0, o_counts = 0, o_sums = 0;
+    bool want_counts = false, want_sums = false, band_ran = false, run_unweighted = false, run_weighted = false;
+    int64_t cand = 0, abytes = 0, n_pot = 0;
+    int launches = 0, kernel = 0, mode = 0, n_orient = 0;
+};
+
+// First half of yawhip_count_pairs on ONE device: everything up to and including the copy of the results into the
+// context's pinned buffer is put on the context's stream; nothing waits for the device (SWEEP's grid sizing aside).
+// job_work != nullptr: cost estimate only -- the item builder runs, evaluated pairs per job are returned, no counting.
+int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                  const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                  bool want_counts, bool want_sums, int64_t *job_work, CallState &cs) {
+    cs = CallState{};
+    cs.wall0 = std::chrono::steady_clock::now();
+    cs.want_counts = want_counts;
+    cs.want_sums = want_sums;
     if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: NULL handle");
     if (c1->ctx != ctx || c2->ctx != ctx) return fail(YAWHIP_ERR_MISMATCH, "catalogues belong to another context");
     if (c1->n_patches != c2->n_patches)
@@ -1956,6 +2002,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const int64_t n_slots = (int64_t)n_jobs * n_bins;
     const int64_t n_out = n_slots * nf;
     const bool weighted = (c1->w != nullptr) || (c2->w != nullptr);
+    cs.n_out = n_out;
     if (n_out == 0) return YAWHIP_OK;
     if (n_slots > (1ll << 30)) return fail(YAWHIP_ERR_INVALID, "too many (job,bin) slots");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -2116,8 +2163,6 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     if (!strip_items) prefix[(size_t)n_pslots] = n_items;
     const int64_t slab = merged ? (int64_t)n_bins * nf : nf;  // float64 values per item of the weighted slab
 
-    const bool want_counts = fine_counts != nullptr;
-    const bool want_sums = fine_sums != nullptr;
     const bool run_weighted = weighted && want_sums;
     const bool run_unweighted = want_counts || (!weighted && want_sums);
 
@@ -2232,7 +2277,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
             n_items = (int64_t)reinterpret_cast<unsigned long long *>(ctx->out.h)[0];
         }
     }
-    if (ctx->job_work_out) {  // cost estimate only: evaluated pairs per job from the item list, no counting
+    if (job_work) {  // cost estimate only: evaluated pairs per job from the item list, no counting
         HIP_TRY(ctx->d_jobwork.reserve((size_t)n_jobs));
         HIP_TRY(hipMemsetAsync(ctx->d_jobwork.ptr, 0, sizeof(unsigned long long) * (size_t)n_jobs, ctx->stream));
         if (n_pot > 0) {
@@ -2240,7 +2285,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                                ctx->d_ctr.ptr, merged ? 1 : n_bins, ctx->d_jobwork.ptr);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemcpyAsync(ctx->job_work_out, ctx->d_jobwork.ptr, sizeof(int64_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
+        HIP_TRY(hipMemcpyAsync(job_work, ctx->d_jobwork.ptr, sizeof(int64_t) * (size_t)n_jobs, hipMemcpyDeviceToHost,
                                ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return YAWHIP_OK;
@@ -2400,32 +2445,184 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     // one copy brings back the counters and whatever was asked for, into pinned memory
     const size_t fetch = want_sums ? out_bytes : (want_counts ? o_sums : o_counts);
     HIP_TRY(hipMemcpyAsync(ctx->out.h, ctx->out.d, fetch, hipMemcpyDeviceToHost, ctx->stream));
+    cs.pending = true;
+    cs.o_ctr = o_ctr; cs.o_counts = o_counts; cs.o_sums = o_sums;
+    cs.band_ran = band_ran; cs.run_unweighted = run_unweighted; cs.run_weighted = run_weighted;
+    cs.cand = cand; cs.abytes = abytes; cs.n_pot = n_pot;
+    cs.launches = launches; cs.kernel = kernel; cs.mode = mode;
+    cs.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
+    return YAWHIP_OK;
+}
+
+// Second half: wait for the context's stream, hand the results (contiguous rows of the jobs given to count_enqueue) and
+// the statistics over.
+int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!cs.pending) {
+        if (fine_counts) memset(fine_counts, 0, sizeof(int64_t) * (size_t)cs.n_out);
+        if (fine_sums) memset(fine_sums, 0, sizeof(double) * (size_t)cs.n_out);
+        return YAWHIP_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (want_counts) memcpy(fine_counts, ctx->out.h + o_counts, sizeof(int64_t) * n_out);
-    if (want_sums) memcpy(fine_sums, ctx->out.h + o_sums, sizeof(double) * n_out);
-    const unsigned long long *ctr = reinterpret_cast<const unsigned long long *>(ctx->out.h + o_ctr);
+    if (fine_counts) memcpy(fine_counts, ctx->out.h + cs.o_counts, sizeof(int64_t) * (size_t)cs.n_out);
+    if (fine_sums) memcpy(fine_sums, ctx->out.h + cs.o_sums, sizeof(double) * (size_t)cs.n_out);
+    const unsigned long long *ctr = reinterpret_cast<const unsigned long long *>(ctx->out.h + cs.o_ctr);
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         float cms = 0.f;
         HIP_TRY(hipEventElapsedTime(&cms, ctx->evc0, ctx->evc1));
         stats->count_ms = cms;
-        stats->candidate_pairs = cand;
-        stats->evaluated_pairs = (int64_t)ctr[1] * ((run_unweighted ? 1 : 0) + (run_weighted ? 1 : 0));
-        if (band_ran) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
+        stats->candidate_pairs = cs.cand;
+        stats->evaluated_pairs = (int64_t)ctr[1] * ((cs.run_unweighted ? 1 : 0) + (cs.run_weighted ? 1 : 0));
+        if (cs.band_ran) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
             unsigned long long ev = 0;
             for (int i = 0; i < EVAL_SLOTS; ++i) ev += ctr[8 + 8 * (size_t)i];
             stats->evaluated_pairs = (int64_t)ev;
         }
-        stats->algorithmic_bytes = abytes;
-        stats->n_workgroups = n_pot > 0 ? (int64_t)ctr[0] : 0;
-        stats->n_launches = launches;
-        stats->kernel_used = kernel;
-        stats->layout_mode = mode;
-        stats->n_orientations = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
+        stats->algorithmic_bytes = cs.abytes;
+        stats->n_workgroups = cs.n_pot > 0 ? (int64_t)ctr[0] : 0;
+        stats->n_launches = cs.launches;
+        stats->kernel_used = cs.kernel;
+        stats->layout_mode = cs.mode;
+        stats->n_orientations = cs.n_orient;
         stats->kernel_ms = ms;
-        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cs.wall0).count();
     }
+    return YAWHIP_OK;
+}
+
+// FNV-1a over the inputs that determine the job partition of a multi-device call
+uint64_t plan_key(const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs, int32_t n_bins,
+                  int32_t n_edges, const double *t, int32_t kernel, size_t n_dev) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    mix(&c1, sizeof c1); mix(&c2, sizeof c2); mix(&c1->n, sizeof c1->n); mix(&c2->n, sizeof c2->n);
+    mix(&n_jobs, sizeof n_jobs); mix(jobs, sizeof(int32_t) * 2 * (size_t)n_jobs);
+    mix(&n_bins, sizeof n_bins); mix(&n_edges, sizeof n_edges); mix(t, sizeof(double) * (size_t)n_bins * n_edges);
+    mix(&kernel, sizeof kernel); mix(&n_dev, sizeof n_dev);
+    return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                       const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                       int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: NULL handle");
+    CallState cs;
+    if (ctx->peers.empty() || n_jobs < 2) {
+        const int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_counts != nullptr,
+                                     fine_sums != nullptr, nullptr, cs);
+        return rc != YAWHIP_OK ? rc : count_finish(ctx, cs, fine_counts, fine_sums, stats);
+    }
+    // ---- several devices: the independent jobs are split over them (replaces the reference's process pool,
+    // src/yaw/utils/parallel.py:251-346). Every device holds both catalogues; a job's rows of the result come from
+    // exactly one device, so nothing has to be reduced: the rows are copied into place.
+    if (c1->ctx != ctx || c2->ctx != ctx) return fail(YAWHIP_ERR_MISMATCH, "catalogues belong to another context");
+    const size_t n_dev = ctx->peers.size() + 1;
+    if (c1->replicas.size() != n_dev - 1 || c2->replicas.size() != n_dev - 1)
+        return fail(YAWHIP_ERR_MISMATCH, "catalogue was not uploaded to every device of the context");
+    if (n_jobs < 0 || n_bins <= 0 || n_edges < 2 || !t || !jobs) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: bad sizes");
+    const auto wall0 = std::chrono::steady_clock::now();
+    // the plan: evaluated pairs per job from the item builder (device 0), longest-processing-time-first over the devices;
+    // it depends on the inputs only and is kept for the next call with the same inputs
+    const uint64_t key = plan_key(c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, n_dev);
+    if (ctx->plan.key != key || ctx->plan.parts.size() != n_dev) {
+        std::vector<int64_t> work((size_t)n_jobs, 0);
+        int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, false, false, work.data(), cs);
+        if (rc != YAWHIP_OK) return rc;
+        std::vector<int32_t> order((size_t)n_jobs);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return work[(size_t)a] > work[(size_t)b]; });
+        std::vector<double> load(n_dev, 0.0);
+        ctx->plan.parts.assign(n_dev, {});
+        const double fixed = 2.0e5;  // evaluated-pair equivalent of touching a job at all
+        for (int32_t j : order) {
+            const size_t d = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            ctx->plan.parts[d].push_back(j);
+            load[d] += (double)work[(size_t)j] + fixed;
+        }
+        for (auto &part : ctx->plan.parts) std::sort(part.begin(), part.end());
+        ctx->plan.key = key;
+    }
+    const int64_t row = (int64_t)n_bins * (n_edges - 1);
+    std::vector<CallState> states(n_dev);
+    std::vector<std::vector<int32_t>> sub(n_dev);
+    for (size_t d = 0; d < n_dev; ++d) {  // enqueue everywhere first: the devices work side by side
+        for (int32_t j : ctx->plan.parts[d]) { sub[d].push_back(jobs[2 * j]); sub[d].push_back(jobs[2 * j + 1]); }
+        yawhip_ctx *dc = d == 0 ? ctx : ctx->peers[d - 1];
+        const yawhip_catalog *a = d == 0 ? c1 : c1->replicas[d - 1], *b = d == 0 ? c2 : c2->replicas[d - 1];
+        const int rc = count_enqueue(dc, a, b, (int32_t)ctx->plan.parts[d].size(), sub[d].data(), n_bins, n_edges, t, kernel,
+                                     fine_counts != nullptr, fine_sums != nullptr, nullptr, states[d]);
+        if (rc != YAWHIP_OK) {
+            for (size_t e = 0; e < d; ++e) (void)hipStreamSynchronize((e == 0 ? ctx : ctx->peers[e - 1])->stream);
+            return rc;
+        }
+    }
+    std::vector<int64_t> rows_c;
+    std::vector<double> rows_s;
+    yawhip_stats total{}, part{};
+    int rc_all = YAWHIP_OK;
+    for (size_t d = 0; d < n_dev; ++d) {
+        yawhip_ctx *dc = d == 0 ? ctx : ctx->peers[d - 1];
+        const size_t nj = ctx->plan.parts[d].size();
+        if (fine_counts) rows_c.resize(nj * (size_t)row);
+        if (fine_sums) rows_s.resize(nj * (size_t)row);
+        const int rc = count_finish(dc, states[d], fine_counts ? rows_c.data() : nullptr, fine_sums ? rows_s.data() : nullptr, &part);
+        if (rc != YAWHIP_OK) { rc_all = rc; continue; }  // keep draining the other devices
+        for (size_t r = 0; r < nj; ++r) {
+            const size_t j = (size_t)ctx->plan.parts[d][r];
+            if (fine_counts) memcpy(fine_counts + j * (size_t)row, rows_c.data() + r * (size_t)row, sizeof(int64_t) * (size_t)row);
+            if (fine_sums) memcpy(fine_sums + j * (size_t)row, rows_s.data() + r * (size_t)row, sizeof(double) * (size_t)row);
+        }
+        total.candidate_pairs += part.candidate_pairs;
+        total.evaluated_pairs += part.evaluated_pairs;
+        total.algorithmic_bytes += part.algorithmic_bytes;
+        total.n_workgroups += part.n_workgroups;
+        total.n_launches += part.n_launches;
+        total.kernel_used = part.kernel_used;
+        total.layout_mode = part.layout_mode;
+        total.n_orientations = std::max(total.n_orientations, part.n_orientations);
+        total.kernel_ms = std::max(total.kernel_ms, part.kernel_ms);  // the devices run side by side: the slowest counts
+        total.count_ms = std::max(total.count_ms, part.count_ms);
+    }
+    if (rc_all != YAWHIP_OK) return rc_all;
+    total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (stats) *stats = total;
+    return YAWHIP_OK;
+}
+
+int yawhip_ctx_create_multi(const int *device_ids, int n_devices, yawhip_ctx **out) {
+    if (!out) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_create_multi: out is NULL");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_create_multi: 1 to 64 device ids");
+    yawhip_ctx *ctx = nullptr;
+    int rc = yawhip_ctx_create(device_ids[0], &ctx);
+    if (rc != YAWHIP_OK) return rc;
+    for (int i = 1; i < n_devices; ++i) {
+        yawhip_ctx *peer = nullptr;
+        rc = yawhip_ctx_create(device_ids[i], &peer);
+        if (rc != YAWHIP_OK) {
+            yawhip_ctx_destroy(ctx);
+            return rc;
+        }
+        ctx->peers.push_back(peer);
+    }
+    *out = ctx;
+    return YAWHIP_OK;
+}
+
+int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n) {
+    if (!ctx || !n) return fail(YAWHIP_ERR_INVALID, "yawhip_ctx_device_count: NULL argument");
+    *n = (int)ctx->peers.size() + 1;
     return YAWHIP_OK;
 }
 
@@ -2475,10 +2672,8 @@ int yawhip_job_work(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_cata
                     int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel, int64_t *work) {
     if (!ctx || !work) return fail(YAWHIP_ERR_INVALID, "yawhip_job_work: NULL argument");
     for (int j = 0; j < n_jobs; ++j) work[j] = 0;
-    ctx->job_work_out = work;
-    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, nullptr, nullptr, nullptr);
-    ctx->job_work_out = nullptr;
-    return rc;
+    CallState cs;
+    return count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, false, false, work, cs);
 }
 
 }  // extern "C"

@@ -9,8 +9,10 @@ from __future__ import annotations
 
 import numpy as np
 
+import os
+
 from . import _lib
-from .parallel import local_device_index
+from .parallel import local_device_index, world
 
 __all__ = ["get_context", "device_catalog", "count_fine", "job_work", "assign_patches", "release", "default_kernel"]
 
@@ -19,11 +21,31 @@ default_kernel = "auto"
 forced_strip_micro: int | None = None  # set to pin the strip grid spacing (bench / experiments)
 
 
-def get_context(device: int | None = None) -> "_lib.Context":
-    device = local_device_index() if device is None else int(device)
-    ctx = _contexts.get(device)
+def default_devices(max_workers: int | None = None) -> tuple:
+    """GPUs one process counts on. Inside a ``torch.distributed`` group (one process per GPU) that is the process'
+    own device; a single process takes every visible GPU (``YAW_AMD_DEVICES="0,1,2"`` picks them explicitly, an id
+    may repeat) -- the counterpart of the reference's worker pool, so ``max_workers`` caps their number
+    (src/yaw/utils/parallel.py:145-150)."""
+    env = os.environ.get("YAW_AMD_DEVICES")
+    if env:
+        devices = [int(v) for v in env.split(",") if v.strip() != ""]
+    elif world()[1] > 1 or "LOCAL_RANK" in os.environ or "YAW_AMD_DEVICE" in os.environ:
+        devices = [local_device_index()]
+    else:
+        devices = list(range(max(_lib.device_count(), 1)))
+    if max_workers is not None and max_workers >= 1:
+        devices = devices[: int(max_workers)]
+    return tuple(devices)
+
+
+def get_context(device=None, max_workers: int | None = None) -> "_lib.Context":
+    """The context of ``device`` (an id or a sequence of ids), by default of :func:`default_devices`."""
+    if device is None:
+        device = default_devices(max_workers)
+    key = tuple(int(d) for d in device) if isinstance(device, (list, tuple)) else (int(device),)
+    ctx = _contexts.get(key)
     if ctx is None:
-        ctx = _contexts[device] = _lib.Context(device)
+        ctx = _contexts[key] = _lib.Context(key[0] if len(key) == 1 else list(key))
     return ctx
 
 
@@ -67,19 +89,21 @@ def device_catalog(layout, ctx=None, sort_axis: int = 2, strip_micro: int | None
     return dev
 
 
-def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None, sort_axis: int = 2):
+def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None, sort_axis: int = 2,
+               max_workers: int | None = None):
     """Fine-bin pair counts for ``jobs`` (int[n,2]) -> (f64[n_jobs, B, E-1], CountStats).
 
     Unweighted catalogues are counted in int64 on the device and converted exactly
-    (the reference's ``.astype(np.float64)``, trees.py:353)."""
-    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis)
+    (the reference's ``.astype(np.float64)``, trees.py:353). With several GPUs in the process' context the library
+    splits the jobs over them; ``max_workers`` caps how many are used."""
+    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis, max_workers)
     counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)
     fine = sums if sums is not None else counts.astype(np.float64)
     return fine, stats
 
 
-def _device_pair(layout1, layout2, thresholds, sort_axis):
-    ctx = get_context()
+def _device_pair(layout1, layout2, thresholds, sort_axis, max_workers=None):
+    ctx = get_context(max_workers=max_workers)
     micro = forced_strip_micro if forced_strip_micro is not None else strip_micro_for(thresholds)
     d1 = device_catalog(layout1, ctx, sort_axis, micro, exact=forced_strip_micro is not None)
     d2 = d1 if layout2 is layout1 else device_catalog(layout2, ctx, sort_axis, d1.strip_micro, exact=True)

@@ -270,31 +270,48 @@ class PatchLinkage:
         plans, thresholds = self._angular_setup()
         num_fine = thresholds.shape[1] - 1
 
-        # shard the independent jobs over the process group (one process per GPU)
+        # Several GPUs, two ways. One process (the drop-in case): the library splits the job list over the devices of
+        # its context, ``max_workers`` caps how many (the reference's worker pool, measurements.py:344-350). One process
+        # per GPU under torch.distributed: the jobs are sharded over the ranks here and one sum all-reduce combines
+        # the result (every slot is non-zero on exactly one rank: the sum is exact and order independent).
         rank, size = parallel.world()
         mine = np.arange(len(jobs))
         if size > 1:
-            # balance what the device will really evaluate (lane tile x window sizes, from the item builder);
-            # the partition is a plan: derived once per (catalogue pair, group size) and reused
+            # balance what the device will really evaluate (lane tile x window sizes, from the item builder); the
+            # partition is a plan: rank 0 derives it once per (catalogue pair, group size) and broadcasts it
             key = (id(layout1), id(layout2), len(layout1.x), len(layout2.x), len(jobs), auto, size)
             if key not in self._partitions:
-                work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
-                self._partitions[key] = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
+                parts = None
+                if rank == 0:
+                    work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
+                    parts = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
+                self._partitions[key] = parallel.broadcast_object(parts)
             mine = self._partitions[key][rank]
-        fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis)
-        self.last_stats = stats
+        failure = None
+        try:
+            fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis,
+                                            max_workers=max_workers)
+            self.last_stats = stats
+        except Exception as err:  # noqa: BLE001 -- with several ranks the others must not wait for this one forever
+            if size == 1:
+                raise
+            failure, fine = err, None
 
-        # fine[b, e, j]: fine-bin counts of every job. With several ranks each one fills its own rows of a
-        # zero-initialised tensor and one sum all-reduce combines them (every slot is non-zero on exactly one
-        # rank, so the sum is exact and order independent).
         id1, id2 = jobs[:, 0], jobs[:, 1]
         if size > 1:
-            # only linked patch pairs carry counts: the tensor travels in its compact [jobs, B, E-1] form
-            # (every rank holds the same job table), 9x smaller than the dense [B, E-1, P, P] at 64 patches
-            compact = np.zeros((len(jobs), num_bins, num_fine), dtype=np.float64)
-            if len(mine):
-                compact[mine] = fine
-            fine_bej = np.moveaxis(parallel.allreduce_sum(compact), 0, -1)
+            # only linked patch pairs carry counts: the tensor travels in its compact [jobs, B, E-1] form (every rank
+            # holds the same job table), 9x smaller than the dense [B, E-1, P, P] at 64 patches; one extra element
+            # carries the number of ranks that failed, so that all of them raise instead of one leaving the rest
+            # blocked in the collective
+            compact = np.zeros(len(jobs) * num_bins * num_fine + 1, dtype=np.float64)
+            if failure is not None:
+                compact[-1] = 1.0
+            elif len(mine):
+                compact[:-1].reshape(len(jobs), num_bins, num_fine)[mine] = fine
+            compact = parallel.allreduce_sum(compact)
+            if compact[-1] > 0:
+                raise RuntimeError(f"pair counting failed on {int(compact[-1])} of {size} ranks") from failure
+            fine_bej = np.moveaxis(compact[:-1].reshape(len(jobs), num_bins, num_fine), 0, -1)
         else:
             fine_bej = np.moveaxis(fine, 0, -1)
 

@@ -12,7 +12,7 @@ import os
 
 import numpy as np
 
-__all__ = ["world", "partition_jobs", "allreduce_sum", "local_device_index"]
+__all__ = ["world", "partition_jobs", "allreduce_sum", "broadcast_object", "local_device_index"]
 
 
 def _dist():
@@ -62,3 +62,14 @@ def allreduce_sum(array: np.ndarray) -> np.ndarray:
         tensor = tensor.to(torch.device("cuda", local_device_index()))
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor.cpu().numpy()
+
+
+def broadcast_object(obj, src: int = 0):
+    """``obj`` of rank ``src`` on every rank (a plan such as the job partition: small, sent once); identity for a
+    single process."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
