@@ -54,6 +54,12 @@ def parse_args():
     return ap.parse_args()
 
 
+def traffic_key(args, kernel_name):
+    """Key of profiles/pmc_traffic.json: the whole workload, not just its size."""
+    return (f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}:p{args.patches}:b{args.zbins}:s{getattr(args, 'scales', 1)}"
+            f":w{int(bool(getattr(args, 'weights', False)))}")
+
+
 # ---------------------------------------------------------------------------------------------- inputs
 def fibonacci_centers(num):
     """num near-uniform points on the sphere (patch centres for the full-sky configs)."""
@@ -150,6 +156,53 @@ def cpu_baseline(links, ref, unk, budget_s):
     )
 
 
+def reference_timing(args):
+    """The reference's OWN count_pairs on this workload, timed in the build container by tools/time_reference.py (the
+    reference cannot travel to the GPU box): seconds and effective candidate pairs/s with its multiprocessing pool on all
+    cores and on one core. None when no run of this configuration is committed."""
+    if getattr(args, "weights", False):
+        return None
+    name = {(10e6, 10e6, 64, 30, 1): "reference_cpu_10Mx10M.json",
+            (50e6, 50e6, 128, 30, 3): "reference_cpu_50Mx50M_3scales.json"}.get(
+        (float(args.n_ref), float(args.n_unk), args.patches, args.zbins, getattr(args, "scales", 1)))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    runs = [r for r in d["runs"] if r.get("count", "DD") == "DD"]
+    best = min(runs, key=lambda r: r["seconds"])
+    out = dict(seconds=best["seconds"], effective_pairs_per_s=d["candidate_pairs"] / best["seconds"], cores=best["workers"],
+               cpu_model=d["cpu_model"], scipy=d["scipy"], where=d["where"], source=f"profiles/{name}",
+               what=d["what"], found_pairs=d["found_pairs"], tree_build_s=d["tree_build_s"])
+    single = [r for r in runs if r["workers"] == 1]
+    if single:
+        out["one_core_seconds"] = single[0]["seconds"]
+    return out
+
+
+def exact_sample(links, ref, unk, n_jobs=2):
+    """The brute-force FP64 kernel (the algorithm the north star describes: every candidate pair, 8 non-FMA FP64 flop)
+    on a few whole jobs of the same workload, inside the same run: its FP64-VALU roofline fraction, and one more parity
+    check of the default path against it."""
+    from yet_another_wizz_amd import engine
+    from yet_another_wizz_amd.measurements import angular_plans, threshold_table
+
+    l1, l2 = ref._active_layout, unk._active_layout
+    jobs = links.get_patch_pairs(ref, unk)[:n_jobs]
+    t = threshold_table(angular_plans(links.config))
+    engine.count_fine(l1, l2, jobs, t, kernel="exact")  # warm
+    f_exact, st = engine.count_fine(l1, l2, jobs, t, kernel="exact")
+    f_default, _ = engine.count_fine(l1, l2, jobs, t)
+    k_s = max(st.count_ms, 1e-9) / 1e3
+    tf = st.candidate_pairs * 8.0 / k_s / 1e12
+    return dict(bound="valu_fp64", kernel="k_count (exact path)", jobs=int(len(jobs)), candidate_pairs=int(st.candidate_pairs),
+                launch_ms=st.count_ms, achieved=tf, peak=FP64_VECTOR_PEAK_TFLOPS / 2.0, unit="TFLOP/s",
+                frac=tf / (FP64_VECTOR_PEAK_TFLOPS / 2.0), pairs_per_s=st.candidate_pairs / k_s,
+                parity_with_default_path=bool(np.array_equal(f_exact, f_default)),
+                note="8 non-FMA FP64 flop per candidate pair against half the FP64 vector peak (SURVEY.md 8(d))")
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -244,43 +297,60 @@ def main():
         count_ms = stats.count_ms if stats.count_ms > 0 else stats.kernel_ms
         k_s = max(count_ms, 1e-9) / 1e3
         kernel_name = {1: "exact", 2: "filter", 3: "sweep", 4: "band"}.get(stats.kernel_used, str(stats.kernel_used))
-        traffic = None
+        # HBM traffic of the count kernel is not measurable from inside this process (rocprofv3 --pmc passes); it is
+        # quoted from the committed PMC run of the SAME configuration and kernel, with its provenance, or left null
+        traffic, traffic_source = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
-                traffic = json.load(f).get(f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}")
+                entry = json.load(f).get(traffic_key(args, kernel_name))
+            if isinstance(entry, dict):
+                traffic = entry.get("bytes")
+                traffic_source = {k: entry.get(k) for k in ("source", "commit", "date", "method")}
         fp64_equiv = stats.candidate_pairs * 8.0 / k_s / 1e12
         hbm_gbps = stats.algorithmic_bytes / k_s / 1e9
         fp32_tflops = stats.evaluated_pairs * 5.0 / k_s / 1e12
         if stats.kernel_used == 1:
             roofline = dict(
                 bound="valu_fp64", achieved=fp64_equiv, peak=FP64_VECTOR_PEAK_TFLOPS / 2.0, unit="TFLOP/s",
-                frac=fp64_equiv / (FP64_VECTOR_PEAK_TFLOPS / 2.0), traffic=traffic,
+                frac=fp64_equiv / (FP64_VECTOR_PEAK_TFLOPS / 2.0), traffic=traffic, traffic_source=traffic_source,
                 note="FP64 vector ALU, no FMA allowed by the parity contract: 8 flop per candidate pair",
             )
         else:
             roofline = dict(
                 bound="hbm", achieved=hbm_gbps, peak=HBM_PEAK_GBPS, unit="GB/s", frac=hbm_gbps / HBM_PEAK_GBPS,
-                traffic=traffic,
+                traffic=traffic, traffic_source=traffic_source,
                 note="algorithmic bytes = per linked patch pair, every object of both patches once (24 B, 32 B "
-                     "weighted); traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE)",
-                fp32_prefilter=dict(evaluated_pairs_per_launch=stats.evaluated_pairs, flop_per_pair=5,
-                                    achieved_tflops=fp32_tflops, peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
-                                    frac=fp32_tflops / FP32_VECTOR_PEAK_TFLOPS),
+                     "weighted); traffic = HBM bytes per launch from the rocprofv3 PMC run named in traffic_source "
+                     "((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes), null if none is committed for this "
+                     "configuration",
+                evaluated=(dict(entries_per_launch=stats.evaluated_pairs, flop_per_entry=8,
+                                achieved_tflops=stats.evaluated_pairs * 8.0 / k_s / 1e12,
+                                peak_tflops=FP64_VECTOR_PEAK_TFLOPS / 2.0,
+                                frac=stats.evaluated_pairs * 8.0 / k_s / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
+                                note="band kernel: every entry of a per-object band is decided by the exact FP64 predicate")
+                           if stats.kernel_used == 4 else
+                           dict(evaluated_pairs_per_launch=stats.evaluated_pairs, flop_per_pair=5,
+                                achieved_tflops=fp32_tflops, peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
+                                frac=fp32_tflops / FP32_VECTOR_PEAK_TFLOPS, note="FP32 pre-filter of the sweep / filter paths")),
                 brute_force_equivalent=dict(achieved_tflops=fp64_equiv, peak_tflops=FP64_VECTOR_PEAK_TFLOPS / 2.0,
                                             frac=fp64_equiv / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
                                             note="candidate pairs x 8 FP64 flop / time; > 1 because culled pairs "
                                                  "are never evaluated"),
             )
         roofline.update(
-            kernel="k_count (exact path)" if stats.kernel_used == 1 else f"k_count_merged ({kernel_name} path)",
+            kernel={1: "k_count (exact path)", 4: "k_count_band (band path)"}.get(stats.kernel_used, f"k_count_merged ({kernel_name} path)"),
             launch_ms=count_ms, all_kernels_ms=stats.kernel_ms,
+            fixed_cost_ms=elapsed / max(args.steps, 1) * 1e3 - count_ms,  # everything of a step that is not the count kernel
             culled_fraction=1.0 - stats.evaluated_pairs / max(stats.candidate_pairs, 1),
             hbm_algorithmic_gbps=hbm_gbps, hbm_peak_gbps=HBM_PEAK_GBPS, hbm_frac=hbm_gbps / HBM_PEAK_GBPS,
         )
         base = None
         if world == 1 and args.cpu_seconds > 0:
             base = cpu_baseline(links, ref, unk, args.cpu_seconds)
+            base["reference"] = reference_timing(args)
+            if stats.kernel_used != 1:
+                roofline["exact_sample"] = exact_sample(links, ref, unk)
         line = dict(
             metric="candidate pairs/s", value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=elapsed / max(args.steps, 1) * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,

@@ -100,6 +100,8 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *   "auto_orient"       1 (default): every job runs on the strip layouts of the orientation (sort axis u, strips along v,
  *                       dropped axis w) that suits its two patches -- w pointing at them; layouts of further
  *                       orientations are built on first use. 0: the sort axis the catalogues were uploaded with
+ *   "slab_budget_bytes" weighted calls keep a slab of partial sums per potential work item; a job list that would need more
+ *                       than this many bytes (default 2^30) is counted in pieces, one after the other (same results)
  *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every
  *                       2^value stages (default 17: 128 lane objects x 160 entries x 2^17 < 2^32; tests lower it) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);

@@ -681,3 +681,32 @@ def test_band_kernel_flush_interval(ctx):
     finally:
         ctx.set_option("flush_stages_log2", 17)
     assert exp.sum() > 0.3 * 3000 * 700
+
+
+@pytest.mark.parametrize("kernel", ["band", "sweep", "filter"])
+def test_weighted_slab_budget_splits_the_job_list(ctx, kernel):
+    """A weighted call keeps a slab of partial sums per potential work item. With a small ``slab_budget_bytes`` the
+    library counts the job list in pieces; the sums do not change by a bit (each job's items are reduced in the same
+    order) and the statistics add up."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(55)
+    P, B = 6, 4
+    c1 = _random_catalog(rng, 20000, P, B, True, dense_box=3.0)
+    c2 = _random_catalog(rng, 25000, P, 1, True, dense_box=3.0)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    lim = oracle.parse_ang_limits(np.array([0.5, 1.58, 5.0]) * np.pi / 10800, np.array([1.58, 5.0, 15.8]) * np.pi / 10800)
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (B, 1))
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    counts0, sums0, st0 = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    assert np.array_equal(counts0, exp_c) and exp_c.sum() > 1e5
+    np.testing.assert_allclose(sums0, exp_s, rtol=RTOL_W, atol=0)
+    try:
+        ctx.set_option("slab_budget_bytes", 4096)  # far below one job's slabs: cut down to single jobs
+        counts1, sums1, st1 = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+    finally:
+        ctx.set_option("slab_budget_bytes", 1 << 30)
+    assert np.array_equal(counts1, counts0) and np.array_equal(sums1, sums0)
+    assert st1.candidate_pairs == st0.candidate_pairs and st1.evaluated_pairs == st0.evaluated_pairs
+    assert st1.n_launches > st0.n_launches

@@ -49,7 +49,13 @@ if "count:FETCH_SIZE" in pmc and "count:WRITE_SIZE" in pmc:
     traffic = (2.0 * mean(pmc["count:FETCH_SIZE"]) + mean(pmc["count:WRITE_SIZE"])) * 1024.0
     tfile = os.path.join(out, "pmc_traffic.json")
     table = json.load(open(tfile)) if os.path.exists(tfile) else {}
-    table[key] = traffic
+    import datetime
+    import subprocess
+
+    commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    table[key] = dict(bytes=traffic, source=f"profiles/{name}_pmc.json", commit=commit or None,
+                      date=datetime.date.today().isoformat(),
+                      method="(2*FETCH_SIZE + WRITE_SIZE)*1024 per count-kernel launch, rocprofv3 --pmc, one counter per pass")
     with open(tfile, "w") as f:
         json.dump(table, f, indent=1)
     print(f"{key}: {traffic:.4g} HBM bytes per count-kernel launch "

@@ -2,6 +2,8 @@
 #   tools/try_variants.sh "-DYAW_MWG=64|--strip-micro 5000 --tile-r 1" "-DYAW_MWG=256|..." ...
 set -e
 cd ${GRAFT_REPO_ROOT:-.}
+# whatever happens, leave the default build behind (build.py also refuses to treat a library built with other flags as fresh)
+trap 'python -c "from yet_another_wizz_amd import build; build.build_library(force=True)"' EXIT
 for round in 1 2; do
 for V in "$@"; do
   FL="${V%%|*}"; OPT=""

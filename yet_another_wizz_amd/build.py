@@ -20,6 +20,7 @@ SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG_DIR, "libyawhip.so")
 OBJ_DIR = os.path.join(PKG_DIR, "build")
+FLAGS_STAMP = os.path.join(OBJ_DIR, "flags.txt")  # the flag set the present objects and library were built with
 
 # -ffp-contract=off: the inclusion predicate must round every product and sum separately (no FMA)
 HIPCC_FLAGS = [
@@ -41,19 +42,36 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: libyawhip.so cannot be built")
 
 
-def is_stale() -> bool:
+def _flag_text(extra_flags=()) -> str:
+    return " ".join([*HIPCC_FLAGS, *extra_flags])
+
+
+def _built_with() -> str | None:
+    try:
+        with open(FLAGS_STAMP) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def is_stale(extra_flags=()) -> bool:
+    """The library is missing, older than a source, or was built with another flag set (an experiment build such as
+    -DYAW_BAND_DIAG must never be mistaken for the product)."""
     if not os.path.exists(LIB):
         return True
     newest = max(os.path.getmtime(p) for p in (*SOURCES, *HEADERS))
-    return os.path.getmtime(LIB) < newest
+    return os.path.getmtime(LIB) < newest or _built_with() != _flag_text(extra_flags)
 
 
 def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     """Compile every source to an object (objects of unchanged sources are reused unless ``force`` or
     ``extra_flags`` are given: the rocPRIM sorts take 30 s, the kernels are what one iterates on) and link."""
-    if not force and not extra_flags and not is_stale():
+    if not force and not is_stale(extra_flags):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
+    flags_changed = _built_with() != _flag_text(extra_flags)
+    if os.path.exists(FLAGS_STAMP):
+        os.remove(FLAGS_STAMP)  # no stamp while the build is incomplete
     hipcc = hipcc_path()
     newest_header = max(os.path.getmtime(p) for p in HEADERS)
     objects = []
@@ -63,7 +81,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
         is_kernels = src == SOURCES[0]
         flags = list(extra_flags) if is_kernels else []  # experiment flags only concern the kernels
         fresh = os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_header)
-        if fresh and not flags and not (force and is_kernels) and not (force == "all"):
+        if fresh and not (is_kernels and (force or flags_changed)) and not (force == "all"):
             continue
         cmd = [hipcc, *HIPCC_FLAGS, *flags, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
         if verbose:
@@ -73,6 +91,8 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(_flag_text(extra_flags))
     return LIB
 
 

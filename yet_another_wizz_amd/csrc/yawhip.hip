@@ -63,6 +63,7 @@ constexpr int64_t SYNC_GRID_MIN_ITEMS = 400000;  // potential items from which t
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr int COUNT_FLUSH_MASK = (1 << 13) - 1;  // k_count: stages between flushes of the 32-bit LDS counters (see there)
 constexpr int MERGED_FLUSH_MASK = (1 << 16) - 1; // k_count_merged: 256 lane objects x 64 streamed objects per stage
+constexpr int SPLIT_JOBS = 1;  // internal status of count_enqueue: nothing was enqueued, the caller must split the job list
 constexpr double PAD_COORD = 4.0;  // padded lanes sit >= 3 away from any unit vector: s >= 9 > max t = 4
 
 thread_local std::string g_last_error;
@@ -1253,6 +1254,7 @@ struct yawhip_ctx {
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     int auto_orient = 1;     // every job runs on the strip layouts of the orientation that suits its patches (0: the catalogues' sort axis)
+    int64_t slab_budget = 1ll << 30;  // bytes of per-item partial sums (weighted calls) above which a job list is cut in two
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
@@ -1773,6 +1775,11 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->auto_orient = value != 0;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "slab_budget_bytes")) {
+        if (value < 4096) return fail(YAWHIP_ERR_INVALID, "slab_budget_bytes must be >= 4096");
+        ctx->slab_budget = value;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "flush_stages_log2")) {
         if (value < 0 || value > 17) return fail(YAWHIP_ERR_INVALID, "flush_stages_log2 must be in [0, 17]");
         ctx->flush_log2 = (int)value;
@@ -2178,6 +2185,12 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     std::vector<double> rwin((size_t)n_bins);
     for (int k = 0; k < n_bins; ++k) rwin[(size_t)k] = std::sqrt(t[(size_t)k * n_edges + n_edges - 1]) * (1.0 + 1e-12) + 1e-15;
     if (merged) rwin[0] = rwin_max;  // one window for all bins of the merged run
+    // A weighted call keeps one slab of partial sums per potential item; long job lists of big catalogues would need
+    // tens of GB (50M x 50M, three scales: 40 GB). Above the budget -- and when the items no longer fit 31 bits -- the
+    // caller cuts the job list in two and counts the halves one after the other (rows of the result are independent).
+    if (n_jobs > 1 && !job_work &&
+        ((run_weighted && n_items * slab * (int64_t)sizeof(double) > ctx->slab_budget) || n_items >= (1ll << 31)))
+        return SPLIT_JOBS;
     if (run_weighted) HIP_TRY(ctx->d_partials.reserve((size_t)std::max<int64_t>(n_items, 1) * slab));
     // layout table of the call: [o] = c1, [3 + o] = c2 for orientation o (plain layouts: entries 0 and 3)
     DevTab h_tabs[6];
@@ -2241,7 +2254,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_pot > 0) {
         if (n_pot >= (1ll << 31))
-            return fail(YAWHIP_ERR_INVALID, "too many work items (%lld)", (long long)n_pot);
+            return fail(YAWHIP_ERR_INVALID, "too many work items (%lld) in one job", (long long)n_pot);
         HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
         unsigned char *kept_flags = nullptr;  // weighted runs of the culling builders: which potential items write a slab
         if (run_weighted && sweep) {
@@ -2493,6 +2506,50 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
     return YAWHIP_OK;
 }
 
+void add_stats(yawhip_stats &total, const yawhip_stats &part, bool side_by_side) {
+    total.candidate_pairs += part.candidate_pairs;
+    total.evaluated_pairs += part.evaluated_pairs;
+    total.algorithmic_bytes += part.algorithmic_bytes;
+    total.n_workgroups += part.n_workgroups;
+    total.n_launches += part.n_launches;
+    total.kernel_used = part.kernel_used;
+    total.layout_mode = part.layout_mode;
+    total.n_orientations = std::max(total.n_orientations, part.n_orientations);
+    if (side_by_side) {  // devices of one call run at the same time: the slowest counts
+        total.kernel_ms = std::max(total.kernel_ms, part.kernel_ms);
+        total.count_ms = std::max(total.count_ms, part.count_ms);
+    } else {             // pieces of one job list on one device run one after the other
+        total.kernel_ms += part.kernel_ms;
+        total.count_ms += part.count_ms;
+    }
+}
+
+// One job list on one device, cut in halves as often as count_enqueue asks for (SPLIT_JOBS).
+int run_single(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs,
+               int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel, int64_t *fine_counts, double *fine_sums,
+               yawhip_stats *stats) {
+    CallState cs;
+    int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_counts != nullptr, fine_sums != nullptr,
+                           nullptr, cs);
+    if (rc == YAWHIP_OK) return count_finish(ctx, cs, fine_counts, fine_sums, stats);
+    if (rc != SPLIT_JOBS) return rc;
+    const int32_t half = n_jobs / 2;
+    const size_t row = (size_t)n_bins * (size_t)(n_edges - 1);
+    yawhip_stats a{}, b{};
+    rc = run_single(ctx, c1, c2, half, jobs, n_bins, n_edges, t, kernel, fine_counts, fine_sums, &a);
+    if (rc != YAWHIP_OK) return rc;
+    rc = run_single(ctx, c1, c2, n_jobs - half, jobs + 2 * (size_t)half, n_bins, n_edges, t, kernel,
+                    fine_counts ? fine_counts + (size_t)half * row : nullptr, fine_sums ? fine_sums + (size_t)half * row : nullptr, &b);
+    if (rc != YAWHIP_OK) return rc;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        add_stats(*stats, a, false);
+        add_stats(*stats, b, false);
+        stats->total_ms = a.total_ms + b.total_ms;
+    }
+    return YAWHIP_OK;
+}
+
 // FNV-1a over the inputs that determine the job partition of a multi-device call
 uint64_t plan_key(const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs, int32_t n_bins,
                   int32_t n_edges, const double *t, int32_t kernel, size_t n_dev) {
@@ -2517,12 +2574,8 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
                        int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
     if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: NULL handle");
-    CallState cs;
-    if (ctx->peers.empty() || n_jobs < 2) {
-        const int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_counts != nullptr,
-                                     fine_sums != nullptr, nullptr, cs);
-        return rc != YAWHIP_OK ? rc : count_finish(ctx, cs, fine_counts, fine_sums, stats);
-    }
+    if (ctx->peers.empty() || n_jobs < 2)
+        return run_single(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_counts, fine_sums, stats);
     // ---- several devices: the independent jobs are split over them (replaces the reference's process pool,
     // src/yaw/utils/parallel.py:251-346). Every device holds both catalogues; a job's rows of the result come from
     // exactly one device, so nothing has to be reduced: the rows are copied into place.
@@ -2537,6 +2590,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const uint64_t key = plan_key(c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, n_dev);
     if (ctx->plan.key != key || ctx->plan.parts.size() != n_dev) {
         std::vector<int64_t> work((size_t)n_jobs, 0);
+        CallState cs;
         int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, false, false, work.data(), cs);
         if (rc != YAWHIP_OK) return rc;
         std::vector<int32_t> order((size_t)n_jobs);
@@ -2556,13 +2610,16 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     const int64_t row = (int64_t)n_bins * (n_edges - 1);
     std::vector<CallState> states(n_dev);
     std::vector<std::vector<int32_t>> sub(n_dev);
+    std::vector<char> later(n_dev, 0);  // shares that have to be cut in pieces: counted after the others, one by one
     for (size_t d = 0; d < n_dev; ++d) {  // enqueue everywhere first: the devices work side by side
         for (int32_t j : ctx->plan.parts[d]) { sub[d].push_back(jobs[2 * j]); sub[d].push_back(jobs[2 * j + 1]); }
         yawhip_ctx *dc = d == 0 ? ctx : ctx->peers[d - 1];
         const yawhip_catalog *a = d == 0 ? c1 : c1->replicas[d - 1], *b = d == 0 ? c2 : c2->replicas[d - 1];
         const int rc = count_enqueue(dc, a, b, (int32_t)ctx->plan.parts[d].size(), sub[d].data(), n_bins, n_edges, t, kernel,
                                      fine_counts != nullptr, fine_sums != nullptr, nullptr, states[d]);
-        if (rc != YAWHIP_OK) {
+        if (rc == SPLIT_JOBS) {
+            later[d] = 1;
+        } else if (rc != YAWHIP_OK) {
             for (size_t e = 0; e < d; ++e) (void)hipStreamSynchronize((e == 0 ? ctx : ctx->peers[e - 1])->stream);
             return rc;
         }
@@ -2573,26 +2630,21 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     int rc_all = YAWHIP_OK;
     for (size_t d = 0; d < n_dev; ++d) {
         yawhip_ctx *dc = d == 0 ? ctx : ctx->peers[d - 1];
+        const yawhip_catalog *a = d == 0 ? c1 : c1->replicas[d - 1], *b = d == 0 ? c2 : c2->replicas[d - 1];
         const size_t nj = ctx->plan.parts[d].size();
         if (fine_counts) rows_c.resize(nj * (size_t)row);
         if (fine_sums) rows_s.resize(nj * (size_t)row);
-        const int rc = count_finish(dc, states[d], fine_counts ? rows_c.data() : nullptr, fine_sums ? rows_s.data() : nullptr, &part);
+        const int rc = later[d] ? run_single(dc, a, b, (int32_t)nj, sub[d].data(), n_bins, n_edges, t, kernel,
+                                             fine_counts ? rows_c.data() : nullptr, fine_sums ? rows_s.data() : nullptr, &part)
+                                : count_finish(dc, states[d], fine_counts ? rows_c.data() : nullptr,
+                                               fine_sums ? rows_s.data() : nullptr, &part);
         if (rc != YAWHIP_OK) { rc_all = rc; continue; }  // keep draining the other devices
         for (size_t r = 0; r < nj; ++r) {
             const size_t j = (size_t)ctx->plan.parts[d][r];
             if (fine_counts) memcpy(fine_counts + j * (size_t)row, rows_c.data() + r * (size_t)row, sizeof(int64_t) * (size_t)row);
             if (fine_sums) memcpy(fine_sums + j * (size_t)row, rows_s.data() + r * (size_t)row, sizeof(double) * (size_t)row);
         }
-        total.candidate_pairs += part.candidate_pairs;
-        total.evaluated_pairs += part.evaluated_pairs;
-        total.algorithmic_bytes += part.algorithmic_bytes;
-        total.n_workgroups += part.n_workgroups;
-        total.n_launches += part.n_launches;
-        total.kernel_used = part.kernel_used;
-        total.layout_mode = part.layout_mode;
-        total.n_orientations = std::max(total.n_orientations, part.n_orientations);
-        total.kernel_ms = std::max(total.kernel_ms, part.kernel_ms);  // the devices run side by side: the slowest counts
-        total.count_ms = std::max(total.count_ms, part.count_ms);
+        add_stats(total, part, true);
     }
     if (rc_all != YAWHIP_OK) return rc_all;
     total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
