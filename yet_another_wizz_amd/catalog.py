@@ -15,9 +15,12 @@ from pathlib import Path
 
 import numpy as np
 
+from . import _threads
 from .binning import Binning
-from .coordinates import AngularCoordinates, AngularDistances, radec_to_xyz
+from .coordinates import AngularCoordinates, AngularDistances
 from .options import Closed
+
+radec_to_xyz = _threads.radec_to_xyz  # numpy's cos / sin on slices of the columns, side by side (same values)
 
 __all__ = ["Catalog", "Patch", "Metadata", "InconsistentPatchesError", "PatchLayout"]
 
@@ -46,16 +49,21 @@ DEVICE_ASSIGN_MIN = 200_000  # below this the host is as fast as a round trip to
 
 
 def nearest_center(xyz, centers_xyz, chunk: int = 1 << 18):
-    """Index of the nearest centre in Euclidean xyz for every object.
+    """Index of the nearest centre in Euclidean xyz for every object; ``xyz`` is an [N, 3] array or a tuple of
+    three columns.
 
     Same rule as ``assign_patch_centers`` (catalog.py:229-249, scipy.cluster.vq.vq): squared
     distance accumulated x, y, z in that order, first minimum wins."""
-    if len(xyz) >= DEVICE_ASSIGN_MIN:  # large inputs: on the GPU if there is one (identical ids, 40x faster)
+    columns = xyz if isinstance(xyz, tuple) else None
+    n = len(columns[0]) if columns is not None else len(xyz)
+    if n >= DEVICE_ASSIGN_MIN:  # large inputs: on the GPU if there is one (identical ids, 40x faster)
         from . import engine
 
-        ids = engine.assign_patches(xyz, centers_xyz)
+        ids = engine.assign_patches(columns if columns is not None else xyz, centers_xyz)
         if ids is not None:
             return ids
+    if columns is not None:
+        xyz = np.column_stack(columns)
     try:
         from scipy.cluster.vq import vq
 
@@ -158,8 +166,18 @@ class Metadata:
         sum_weights = float(len(coords)) if weights is None else float(np.sum(weights))
         if xyz is None:
             xyz = coords.to_3d()
-        centre = center.copy() if center is not None else AngularCoordinates.from_3d(np.average(xyz, weights=weights, axis=0))
-        radius = AngularDistances.from_3d(np.sqrt(((xyz - centre.to_3d()) ** 2).sum(axis=1))).max()
+        if isinstance(xyz, tuple):  # three columns: the same numbers without an [N, 3] copy
+            x, y, z = xyz
+            if center is not None:
+                centre = center.copy()
+            else:  # the reference averages the rows of the [N, 3] array: same call, same summation order
+                centre = AngularCoordinates.from_3d(np.average(np.column_stack(xyz), weights=weights, axis=0))
+            cx, cy, cz = centre.to_3d()[0]
+            chord = np.sqrt(((x - cx) ** 2 + (y - cy) ** 2) + (z - cz) ** 2)  # = ((xyz - c) ** 2).sum(axis=1): left to right
+        else:
+            centre = center.copy() if center is not None else AngularCoordinates.from_3d(np.average(xyz, weights=weights, axis=0))
+            chord = np.sqrt(((xyz - centre.to_3d()) ** 2).sum(axis=1))
+        radius = AngularDistances.from_3d(chord).max()
         return cls(num_records=len(coords), sum_weights=sum_weights, center=centre, radius=radius)
 
     def to_dict(self) -> dict:
@@ -312,36 +330,41 @@ class Catalog(Mapping):
             empty = np.flatnonzero(sizes == 0).tolist()
             raise ValueError(f"empty patches are not supported (patch ids {empty})")
         order = _stable_argsort_small(patch_ids, num)
-        self._ra, self._dec = ra[order], dec[order]
-        self._w = None if weights is None else np.asarray_chkfinite(weights, dtype=np.float64)[order]
-        self._z = None if redshifts is None else np.asarray_chkfinite(redshifts, dtype=np.float64)[order]
+        if np.all(patch_ids[1:] >= patch_ids[:-1]):
+            order = None  # already grouped by patch (a restored cache): the stable order is the identity, no gather
+        take = (lambda c: c) if order is None else (lambda c: _threads.take(c, order))
+        self._ra, self._dec = take(ra), take(dec)
+        self._w = None if weights is None else take(np.asarray_chkfinite(weights, dtype=np.float64))
+        self._z = None if redshifts is None else take(np.asarray_chkfinite(redshifts, dtype=np.float64))
         self._patch_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         # unit vectors: computed once per catalogue (assignment, patch metadata and the device layouts all use
         # these values -- the exact host numbers the pair predicate runs on)
-        self._xyz = radec_to_xyz(self._ra, self._dec) if xyz is None else tuple(np.asarray(c)[order] for c in xyz)
-        need_meta = not stored_meta or any(pid not in stored_meta for pid in range(num))
-        xyz_rows = np.column_stack(self._xyz) if need_meta else None
+        self._xyz = radec_to_xyz(self._ra, self._dec) if xyz is None else tuple(take(np.asarray(c)) for c in xyz)
         self._layouts: dict = {}
         self._active_layout = None
         self.cache_directory = None if cache_directory is None else Path(cache_directory)
         if patch_centers is not None and len(patch_centers) != num:
             raise ValueError("number of patch centers does not match the number of patches")
-        self._patches = {}
-        for pid in range(num):
+
+        def patch_meta(pid):
             lo, hi = int(self._patch_off[pid]), int(self._patch_off[pid + 1])
-            coords = AngularCoordinates(np.column_stack([self._ra[lo:hi], self._dec[lo:hi]]))
             if stored_meta and pid in stored_meta:  # meta.yml of the cache (patch.py:359-362)
                 m = stored_meta[pid]
-                meta = Metadata(num_records=int(m["num_records"]), sum_weights=float(m["sum_weights"]),
+                return Metadata(num_records=int(m["num_records"]), sum_weights=float(m["sum_weights"]),
                                 center=AngularCoordinates(m["center"]), radius=AngularDistances(m["radius"]))
-            else:
-                meta = Metadata.compute(
-                    coords,
-                    weights=None if self._w is None else self._w[lo:hi],
-                    center=None if patch_centers is None else patch_centers[pid],
-                    xyz=xyz_rows[lo:hi],
-                )
-            self._patches[pid] = Patch(self, lo, hi, meta)
+            return Metadata.compute(
+                range(hi - lo),  # only its length is used when the unit vectors are given
+                weights=None if self._w is None else self._w[lo:hi],
+                center=None if patch_centers is None else patch_centers[pid],
+                xyz=tuple(c[lo:hi] for c in self._xyz),
+            )
+
+        if len(ra) >= _threads.MIN_PARALLEL and _threads.pool_size() > 1:  # patches are independent
+            metas = list(_threads._executor().map(patch_meta, range(num)))
+        else:
+            metas = [patch_meta(pid) for pid in range(num)]
+        self._patches = {pid: Patch(self, int(self._patch_off[pid]), int(self._patch_off[pid + 1]), metas[pid])
+                         for pid in range(num)}
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -380,7 +403,7 @@ class Catalog(Mapping):
         xyz = None
         if centers is not None:
             xyz = radec_to_xyz(ra, dec)
-            patch_ids = nearest_center(np.column_stack(xyz), centers.to_3d())
+            patch_ids = nearest_center(xyz, centers.to_3d())
             num = len(centers)
         new = cls._from_columns(ra, dec, patch_ids=patch_ids, num_patches=num, weights=weights, redshifts=redshifts,
                                 patch_centers=centers, cache_directory=None, xyz=xyz)
@@ -532,8 +555,8 @@ class Catalog(Mapping):
             order = keep[_stable_argsort_small(seg_key, num_patches * num_bins)]
             offsets = np.zeros(num_patches * num_bins + 1, dtype=np.int64)
             np.cumsum(np.bincount(seg_key, minlength=num_patches * num_bins), out=offsets[1:])
-            layout = PatchLayout(x[order], y[order], z[order], None if self._w is None else self._w[order], offsets,
-                                 num_patches, num_bins)
+            layout = PatchLayout(_threads.take(x, order), _threads.take(y, order), _threads.take(z, order),
+                                 None if self._w is None else _threads.take(self._w, order), offsets, num_patches, num_bins)
         self._layouts[key] = layout
         self._active_layout = layout  # what the next count_pairs() uses, like the cached trees.pkl
         return layout

@@ -128,7 +128,10 @@ def assign_patches(xyz, centers_xyz):
         ctx = get_context()
     except _lib.YawhipError:
         return None
-    xyz = np.asarray(xyz, dtype=np.float64)
-    ids = _lib.assign_patches(ctx, np.ascontiguousarray(xyz[:, 0]), np.ascontiguousarray(xyz[:, 1]),
-                              np.ascontiguousarray(xyz[:, 2]), centers_xyz)
+    if isinstance(xyz, tuple):  # three columns
+        x, y, z = (np.ascontiguousarray(c, dtype=np.float64) for c in xyz)
+    else:
+        xyz = np.asarray(xyz, dtype=np.float64)
+        x, y, z = (np.ascontiguousarray(xyz[:, a]) for a in range(3))
+    ids = _lib.assign_patches(ctx, x, y, z, centers_xyz)
     return ids.astype(np.int64)
