@@ -108,15 +108,19 @@ struct alignas(16) ObjF {  // its float32 image for the pre-filter: one 16-byte 
 constexpr double FILTER_GUARD = 8.0 * 5.9604644775390625e-8;
 constexpr double UNIT_NORM_TOL = 1e-9;
 
-struct alignas(16) Item {  // one unit of work for a workgroup
+constexpr int MAX_WIN = 3;  // windows (partner runs of c1) one work item can carry
+struct alignas(16) Item {  // one unit of work for a workgroup: a lane tile of c2 and up to MAX_WIN windows of c1
     int64_t a0;    // first lane object (c2 side)
-    int64_t b0;    // first streamed object (c1 side)
-    int32_t na;    // lane objects (<= 256*R, <= 64*R on the SWEEP path)
-    int32_t nb;    // streamed objects
+    int32_t na;    // lane objects (<= 256*R, <= 64*R on the SWEEP / BAND paths)
     int32_t slot;  // output slot: job * n_bins + bin, or the job itself on the strip path (bits 0..29);
                    // bits 30..31: orientation = which of the catalogues' three strip layouts a0 / b0 index
     int32_t pot;   // index among all potential items (slab index of weighted partial sums)
+    int32_t nwin;  // windows in use (>= 1 for a kept item)
+    int64_t b0[MAX_WIN];  // first streamed object of every window (c1 side)
+    int32_t nb[MAX_WIN];  // streamed objects of every window
+    int32_t pad_;
 };
+static_assert(sizeof(Item) == 64, "Item layout");
 constexpr int SLOT_MASK = 0x3fffffff;
 __host__ __device__ inline int item_slot(const Item &it) { return it.slot & SLOT_MASK; }
 __host__ __device__ inline int item_orient(const Item &it) { return (int)((unsigned)it.slot >> 30); }
@@ -151,6 +155,7 @@ __device__ __forceinline__ gf64p tab_key(const DevTab &t) { return t.axis == 0 ?
 //                  dropped; survivors are appended with one atomic per workgroup (order is irrelevant).
 // ------------------------------------------------------------------------------------------------
 constexpr int BUILD_WG = 1024;  // threads per workgroup of the item builders
+constexpr int BUILD_PREFIX_LDS = 4096;  // job tables up to this many entries are searched in LDS by the strip builder
 
 // Append the kept items of a builder workgroup to the item list and add its evaluated-pair total: ONE atomic
 // per workgroup on each of the two counters. (They are single hot addresses -- with an atomic per wave the
@@ -224,8 +229,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
             b1 = l;
         }
         keep = b1 > b0;
-        it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0); it.slot = slot; it.pot = (int32_t)pot;
-        work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
+        it.a0 = a0; it.b0[0] = b0; it.na = (int32_t)(a1 - a0); it.nb[0] = (int32_t)(b1 - b0); it.nwin = 1; it.slot = slot; it.pot = (int32_t)pot;
+        work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb[0] : 0ull;
     }
     if (SWEEP) {
         append_items(keep, it, work, items, counters, kept);
@@ -253,68 +258,101 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
     bool keep = false;
     Item it{};
     unsigned long long work = 0;
+    // Every thread walks a chain of dependent loads (job -> run -> tile -> windows); its length is the kernel's run time.
+    // The job table is small: searched in LDS (one coalesced load instead of log2(jobs) round trips to L2).
+    __shared__ int64_t s_prefix[BUILD_PREFIX_LDS];
+    const bool prefix_in_lds = n_jobs + 1 <= BUILD_PREFIX_LDS;
+    if (prefix_in_lds) {
+        for (int e = threadIdx.x; e <= n_jobs; e += blockDim.x) s_prefix[e] = prefix[e];
+        __syncthreads();
+    }
     if (pot < n_pot) {
         int lo = 0, hi = n_jobs;  // job = largest j with prefix[j] <= pot
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (prefix[mid] <= pot) lo = mid; else hi = mid;
+        if (prefix_in_lds) {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= pot) lo = mid; else hi = mid;
+            }
+        } else {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (prefix[mid] <= pot) lo = mid; else hi = mid;
+            }
         }
         const int job = lo, p = jobs[2 * job], q = jobs[2 * job + 1];
         const int o = job_runs[3 * job + 2];  // orientation of the job: which pair of layouts it runs on
         const DevTab &c1 = tabs[o], &c2 = tabs[3 + o];
         const gf64p key1 = tab_key(c1), key2 = tab_key(c2);
-        // potential items of a job, in this order: run of patch q, neighbour offset d, lane tile of the run.
-        // Consecutive items then stream adjacent windows of one c1 run and the three visits of a lane
-        // tile stay close in time (both sides hit in L2).
-        const int nd = 2 * reach + 1;
+        // potential items of a job, in this order: run of patch q, group of neighbour offsets, lane tile of the run. One
+        // item carries up to MAX_WIN neighbouring strips of patch p (all 2 * reach + 1 = 3 of them when the grid is as
+        // wide as the largest separation): the lane tile is loaded once and its histogram flushed once for all of them.
+        const int nd = 2 * reach + 1, ng = (nd + MAX_WIN - 1) / MAX_WIN;
         // runs of patch q whose grid index is within reach of some strip of patch p (host: job_runs)
         const int64_t r_lo = c2.vbase[q] + job_runs[3 * job], r_hi = r_lo + job_runs[3 * job + 1];
         const int64_t t_lo = c2.tiles[r_lo];
-        const int64_t local = pot - prefix[job];
-        int64_t l = r_lo, h = r_hi;  // run = largest r in [r_lo, r_hi) with nd * tiles-before-r <= local (skips empty runs)
+        const int64_t local = pot - (prefix_in_lds ? s_prefix[job] : prefix[job]);
+        int64_t l = r_lo, h = r_hi;  // run = largest r in [r_lo, r_hi) with ng * tiles-before-r <= local (skips empty runs)
         while (h - l > 1) {
             const int64_t m = (l + h) >> 1;
-            if ((c2.tiles[m] - t_lo) * nd <= local) l = m; else h = m;
+            if ((c2.tiles[m] - t_lo) * ng <= local) l = m; else h = m;
         }
         const int64_t r2 = l;
         const int64_t run_tiles = c2.tiles[r2 + 1] - c2.tiles[r2];
-        const int64_t in_run = local - (c2.tiles[r2] - t_lo) * nd;
-        const int d = (int)(in_run / run_tiles) - reach;
+        const int64_t in_run = local - (c2.tiles[r2] - t_lo) * ng;
+        const int g = (int)(in_run / run_tiles);
         const int64_t target = c2.tiles[r2] + in_run % run_tiles;
-        const int64_t s1 = c2.slo[q] + (r2 - c2.vbase[q]) + d - c1.slo[p];
-        if (s1 >= 0 && s1 < c1.vbase[p + 1] - c1.vbase[p]) {
-            const int64_t r1 = c1.vbase[p] + s1;
-            int64_t b0 = c1.off[r1], b1 = c1.off[r1 + 1];
-            const int64_t a_seg1 = c2.off[r2 + 1];
-            const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
-            const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
-            if (b1 > b0) {
-                const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
-                // four potential items in five pair a lane tile with a run that lies entirely before or behind its
-                // window (neighbouring patches share a boundary only): two loads settle those
-                if (key1[b1 - 1] < wlo || key1[b0] > whi) {
-                    b1 = b0;
-                } else {
-                    l = b0; h = b1;  // first index with key >= wlo
-                    while (l < h) {
-                        const int64_t m = (l + h) >> 1;
-                        if (key1[m] < wlo) l = m + 1; else h = m;
-                    }
-                    const int64_t first = l;
-                    h = b1;  // first index with key > whi
-                    while (l < h) {
-                        const int64_t m = (l + h) >> 1;
-                        if (key1[m] <= whi) l = m + 1; else h = m;
-                    }
-                    b0 = first;
-                    b1 = l;
-                }
-            }
-            keep = b1 > b0;
-            it.a0 = a0; it.b0 = b0; it.na = (int32_t)(a1 - a0); it.nb = (int32_t)(b1 - b0);
-            it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
-            work = keep ? (unsigned long long)it.na * (unsigned long long)it.nb : 0ull;
+        const int64_t a_seg1 = c2.off[r2 + 1];
+        const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
+        const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
+        const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
+        const int64_t n_strips1 = c1.vbase[p + 1] - c1.vbase[p];
+        it.a0 = a0; it.na = (int32_t)(a1 - a0); it.nwin = 0;
+        it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
+        // The windows of the (up to) three partner runs are searched in lockstep: three independent chains of loads per
+        // thread instead of one after the other (static indices throughout: everything stays in registers).
+        int64_t wb[MAX_WIN], sl[MAX_WIN], sh[MAX_WIN], ul[MAX_WIN], uh[MAX_WIN];
+        int32_t wn[MAX_WIN];
+#pragma unroll
+        for (int j = 0; j < MAX_WIN; ++j) {
+            const int dd = g * MAX_WIN + j;
+            const int64_t s1 = c2.slo[q] + (r2 - c2.vbase[q]) + (dd - reach) - c1.slo[p];
+            const bool valid = dd < nd && s1 >= 0 && s1 < n_strips1;
+            const int64_t r1 = c1.vbase[p] + (valid ? s1 : 0);
+            const int64_t b0 = c1.off[r1], b1 = valid ? c1.off[r1 + 1] : b0;
+            // four partner runs in five lie entirely before or behind the tile's window (neighbouring patches share a
+            // boundary only): two loads settle those
+            const bool some = b1 > b0;
+            const double kfirst = key1[some ? b0 : 0], klast = key1[some ? b1 - 1 : 0];
+            const bool live = some && !(klast < wlo || kfirst > whi);
+            sl[j] = ul[j] = b0;
+            sh[j] = uh[j] = live ? b1 : b0;
         }
+        // lower bounds (first index with key >= wlo) and upper bounds (first index with key > whi), all at once
+        while ((sl[0] < sh[0]) | (sl[1] < sh[1]) | (sl[2] < sh[2]) | (ul[0] < uh[0]) | (ul[1] < uh[1]) | (ul[2] < uh[2])) {
+#pragma unroll
+            for (int j = 0; j < MAX_WIN; ++j) {
+                const bool gl = sl[j] < sh[j], gu = ul[j] < uh[j];
+                const int64_t ml = (sl[j] + sh[j]) >> 1, mu = (ul[j] + uh[j]) >> 1;
+                const double kl = key1[gl ? ml : 0], ku = key1[gu ? mu : 0];
+                if (gl) { if (kl < wlo) sl[j] = ml + 1; else sh[j] = ml; }
+                if (gu) { if (ku <= whi) ul[j] = mu + 1; else uh[j] = mu; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAX_WIN; ++j) {
+            wb[j] = sl[j];
+            wn[j] = (int32_t)(ul[j] - sl[j]);  // 0 for a dead window (both bounds stay at b0)
+        }
+#pragma unroll
+        for (int j = 0; j < MAX_WIN; ++j) {  // non-empty windows to the front
+            if (wn[j] <= 0) continue;
+            if (it.nwin == 0) { it.b0[0] = wb[j]; it.nb[0] = wn[j]; }
+            else if (it.nwin == 1) { it.b0[1] = wb[j]; it.nb[1] = wn[j]; }
+            else { it.b0[2] = wb[j]; it.nb[2] = wn[j]; }
+            ++it.nwin;
+            work += (unsigned long long)it.na * (unsigned long long)wn[j];
+        }
+        keep = it.nwin > 0;
     }
     append_items(keep, it, work, items, counters, kept);
 }
@@ -354,7 +392,7 @@ __global__ __launch_bounds__(WG) void k_count(CatView c1, CatView c2, const Item
     const Item it = items[item_base + blockIdx.x];
     const int slot = it.slot;
     const int k = slot % n_bins;
-    const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
+    const int64_t b0 = it.b0[0], b1 = it.b0[0] + it.nb[0];  // items of k_build_items carry one window
     const int64_t a0 = it.a0, a_seg1 = it.a0 + it.na;
     const int64_t item = it.pot;
 
@@ -579,7 +617,7 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
     const int nkb = MERGED ? n_bins : 1;             // bins this item can add to
     const int nslots = nkb * nf;
     const double rwin = rwin_k[kfix];
-    const int64_t b0 = it.b0, b1 = it.b0 + it.nb;
+    int64_t b0 = it.b0[0], b1 = it.b0[0] + it.nb[0];  // the current window (an item of the strip builder carries up to three)
     const int64_t a0 = it.a0, a_end = it.a0 + it.na;
     // wave-contiguous assignment: wave w owns objects [w*64R, (w+1)*64R) of the z-sorted tile, so its
     // own z-window is narrower than the workgroup's
@@ -587,11 +625,11 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
 
     // Everything the item needs from global memory is requested here, back to back, before the first use:
     // lane objects, the key range of the wave, the first stage of the stream, thresholds (one memory latency).
-    const int64_t nb_total = b1 - b0;
+    int64_t nb_total = b1 - b0;
 #ifdef YAW_DIAG_SKIP_STREAM
-    const int nstages = 0;  // diagnostics: per-item fixed cost only (wrong counts)
+    int nstages = 0;  // diagnostics: per-item fixed cost only (wrong counts)
 #else
-    const int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
+    int nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
 #endif
     constexpr int NPF = (MSTAGE + MWG - 1) / MWG;  // stage slots a thread fills
     struct Raw { double x, y, z; int k; bool in; };
@@ -680,6 +718,22 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
         }
     };
     int qn = 0;  // entries in this wave's survivor queue (wave-uniform)
+    for (int win = 0; win < it.nwin; ++win) {
+    if (win > 0) {  // next window of the item: its first stage goes through the same double buffer
+        b0 = win == 1 ? it.b0[1] : it.b0[2];
+        b1 = b0 + (win == 1 ? it.nb[1] : it.nb[2]);
+        nb_total = b1 - b0;
+#ifndef YAW_DIAG_SKIP_STREAM
+        nstages = (int)((nb_total + MSTAGE - 1) / MSTAGE);
+#endif
+#pragma unroll
+        for (int f = 0; f < NPF; ++f) first[f] = fetch_raw(b0 + f * MWG + tid);
+        __syncthreads();  // every lane is done with the previous window's last stage
+#pragma unroll
+        for (int f = 0; f < NPF; ++f)
+            if (f * MWG + tid < MSTAGE) stagef[f * MWG + tid] = finish(first[f]);
+        __syncthreads();
+    }
     for (int st = 0; st < nstages; ++st) {
         const int cb = st & 1;
         const int64_t sb0 = b0 + (int64_t)st * MSTAGE;  // global index of stage slot 0
@@ -825,6 +879,11 @@ __device__ __forceinline__ void count_merged_body(const DevTab *__restrict__ tab
             __syncthreads();
         }
     }
+    if (!WEIGHTED && nstages > MERGED_FLUSH_MASK / 4 && win + 1 < it.nwin) {  // a long window: do not carry its counts into the next
+        flush_hist();
+        __syncthreads();
+    }
+    }
 
     flush_hist();
 }
@@ -949,7 +1008,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);  // sort-axis column of the stage
         const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
-        const int64_t b0 = it.b0, nb_total = it.nb;
+        int64_t b0 = it.b0[0], nb_total = it.nb[0];  // the current window (an item of the strip builder carries up to three)
 
         __syncthreads();  // the previous item of this workgroup has left the LDS
         // stage of the window -> LDS, 16 bytes per lane and instruction; lanes past the stage stay out of it.
@@ -1020,9 +1079,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             }
         };
 
+        for (int win = 0; win < it.nwin; ++win) {
+        if (win > 0) {
+            b0 = win == 1 ? it.b0[1] : it.b0[2];
+            nb_total = win == 1 ? it.nb[1] : it.nb[2];
+        }
         for (int64_t st0 = 0; st0 < nb_total; st0 += BCAP, ++stage_no) {
             const int n = (int)(nb_total - st0 < BCAP ? nb_total - st0 : BCAP);
-            if (st0 > 0) {
+            if (st0 > 0 || win > 0) {
                 __syncthreads();  // every lane is done with the previous stage
                 stage_in(st0, n);
             }
@@ -1132,6 +1196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             // 64*R lane objects x BCAP entries per stage: a uint32 counter cannot wrap within flush_mask + 1 stages
             if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush();
         }
+        }
         flush();
         // evaluated band entries of the item -> one of EVAL_SLOTS counters (statistics)
         for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
@@ -1145,7 +1210,9 @@ __global__ void k_item_work(const Item *__restrict__ items, const unsigned long 
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= counters[0]) return;
     const Item it = items[i];
-    atomicAdd(&job_work[item_slot(it) / slots_per_job], (unsigned long long)it.na * (unsigned long long)it.nb);
+    unsigned long long streamed = 0;
+    for (int w = 0; w < it.nwin; ++w) streamed += (unsigned long long)it.nb[w];
+    atomicAdd(&job_work[item_slot(it) / slots_per_job], (unsigned long long)it.na * streamed);
 }
 
 // Weighted sums: every kept item left a slab of `slab` float64 values at partials[pot]. They are added per output
@@ -2106,8 +2173,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
 
     // item table: prefix[slot] = first item of the slot; items of a slot are its lane tiles.
     // standard path: slot = (job, bin); merged path: slot = job (one item covers all bins).
-    // strip path: slot = job; its potential items = (lane tiles of patch q) x (2*reach+1 neighbouring strips),
-    // enumerated by the builder kernel from the catalogues' run tables.
+    // strip path: slot = job; its potential items = (lane tiles of patch q) x (groups of up to MAX_WIN of the 2*reach+1
+    // neighbouring strips), enumerated by the builder kernel from the catalogues' run tables.
     std::vector<int64_t> prefix;
     std::vector<int32_t> job_runs;  // strip path, per job: first run of patch q (relative) and number of runs to visit
     int64_t n_items = 0, cand = 0, abytes = 0;
@@ -2146,7 +2213,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 const int64_t r0 = sl2.h_vbase[(size_t)q] + s_lo;
                 job_runs[(size_t)3 * j] = (int32_t)s_lo;
                 job_runs[(size_t)3 * j + 1] = (int32_t)(s_hi - s_lo + 1);
-                n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * (2 * reach + 1);
+                n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * ((2 * reach + 1 + MAX_WIN - 1) / MAX_WIN);
             }
         }
         prefix[(size_t)n_sjobs] = n_items;
