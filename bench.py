@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--tile-r", type=int, default=0, help="objects per lane (0 = library default)")
     ap.add_argument("--debug-no-hits", action="store_true", help="diagnostics: time the pre-filter only (wrong counts)")
     ap.add_argument("--strip-micro", type=int, default=None, help="strip grid spacing in 1e-6 chord units (0 = no strips)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="library tunable (yawhip_ctx_set_option), e.g. band_grid_div=2")
     ap.add_argument("--scales", type=int, default=1, choices=[1, 3],
                     help="1: one scale 1-10 arcmin; 3: the log-spaced scales of BASELINE config #5 (0.5-15.8 arcmin)")
     ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5) on both catalogues")
@@ -247,6 +248,9 @@ def main():
         engine.get_context().set_option("debug_no_hits", 1)
     if args.strip_micro is not None:
         engine.forced_strip_micro = args.strip_micro
+    for item in args.set:
+        key, value = item.split("=", 1)
+        engine.get_context().set_option(key, int(value))
     inputs = make_inputs(args)
     t_setup = time.perf_counter()  # catalogue set-up: unit vectors, patch assignment, (patch, bin) layouts, linkage
     config, ref, unk = make_catalogs(args, inputs)

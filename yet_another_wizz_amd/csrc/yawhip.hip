@@ -1322,6 +1322,8 @@ struct yawhip_ctx {
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     int auto_orient = 1;     // every job runs on the strip layouts of the orientation that suits its patches (0: the catalogues' sort axis)
     int64_t slab_budget = 1ll << 30;  // bytes of per-item partial sums (weighted calls) above which a job list is cut in two
+    int band_grid_div = 4;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest;
+                             // 1, 2, 4 and 8 measure the same at the headline)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
@@ -1847,6 +1849,11 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->slab_budget = value;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "band_grid_div")) {
+        if (value < 1 || value > 64) return fail(YAWHIP_ERR_INVALID, "band_grid_div must be in [1, 64]");
+        ctx->band_grid_div = (int)value;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "flush_stages_log2")) {
         if (value < 0 || value > 17) return fail(YAWHIP_ERR_INVALID, "flush_stages_log2 must be in [0, 17]");
         ctx->flush_log2 = (int)value;
@@ -2221,18 +2228,27 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         prefix.resize((size_t)n_slots + 1);
     }
     const int64_t n_pslots = merged ? (int64_t)n_jobs : n_slots;
+    auto patch_total = [](const yawhip_catalog *c, int patch) {  // objects of a patch over all its bins
+        return c->h_off[(size_t)(patch + 1) * c->nb] - c->h_off[(size_t)patch * c->nb];
+    };
     for (int j = 0; j < n_jobs; ++j) {
-        for (int k = 0; k < n_bins; ++k) {
-            const int64_t n1 = seg_len(c1, jobs[2 * j], k), n2 = seg_len(c2, jobs[2 * j + 1], k);
-            if (!strip_items) prefix[(size_t)j * n_bins + k] = n_items;
-            if (n1 > 0 && n2 > 0) {
-                if (!strip_items) n_items += (n2 + tile - 1) / tile;
-                cand += n1 * n2;
+        const int p = jobs[2 * j], q = jobs[2 * j + 1];
+        if (strip_items && (c1->nb == 1 || c2->nb == 1)) {
+            // an unbinned side is one segment used for every bin: sum_k N1(p,k) N2(q,k) factorises
+            cand += c1->nb == 1 ? patch_total(c1, p) * patch_total(c2, q) * (c2->nb == 1 ? n_bins : 1)
+                                : patch_total(c1, p) * patch_total(c2, q);
+        } else {
+            for (int k = 0; k < n_bins; ++k) {
+                const int64_t n1 = seg_len(c1, p, k), n2 = seg_len(c2, q, k);
+                if (!strip_items) prefix[(size_t)j * n_bins + k] = n_items;
+                if (n1 > 0 && n2 > 0) {
+                    if (!strip_items) n_items += (n2 + tile - 1) / tile;
+                    cand += n1 * n2;
+                }
             }
         }
         // algorithmic bytes of a job = every object of the two patches once (Bobj * (N1 + N2))
-        for (int k = 0; k < c1->nb; ++k) abytes += seg_len(c1, jobs[2 * j], k) * obj_bytes1;
-        for (int k = 0; k < c2->nb; ++k) abytes += seg_len(c2, jobs[2 * j + 1], k) * obj_bytes2;
+        abytes += patch_total(c1, p) * obj_bytes1 + patch_total(c2, q) * obj_bytes2;
     }
     if (!strip_items) prefix[(size_t)n_pslots] = n_items;
     const int64_t slab = merged ? (int64_t)n_bins * nf : nf;  // float64 values per item of the weighted slab
@@ -2398,7 +2414,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // Grid from the number of POTENTIAL items (known on the host); the kernel reads the number the builder kept
         // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
         // The strip builder keeps about one potential item in five, ordinary items are all kept.
-        int64_t grid = strip_items && n_pot > 65536 ? n_pot / 4 : n_pot;
+        int64_t grid = strip_items && n_pot > 65536 ? n_pot / std::max(ctx->band_grid_div, 1) : n_pot;
         grid = std::min<int64_t>((grid + 7) & ~7ll, 1ll << 22);
         const unsigned flush_mask = (1u << ctx->flush_log2) - 1u;
         auto launch_band = [&](bool wgt) -> hipError_t {
