@@ -39,12 +39,13 @@ typedef enum yawhip_status {
 
 /* Which device code path counts the pairs. All of them return identical results. */
 typedef enum yawhip_kernel {
-    YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path */
+    YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path: BAND on strip layouts whose streamed runs are dense,
+                                 SWEEP otherwise (stats->kernel_used tells) */
     YAWHIP_KERNEL_EXACT = 1,  /* plain FP64 brute force over every candidate pair */
     YAWHIP_KERNEL_FILTER = 2, /* FP32 guard-banded pre-filter, FP64 re-evaluation of survivors */
     YAWHIP_KERNEL_SWEEP = 3,  /* FILTER + sorted-axis sweep that skips far-away tile pairs */
     YAWHIP_KERNEL_BAND = 4    /* sorted-axis windows as SWEEP, then per-object bands inside the window evaluated
-                                 directly in FP64 (no pre-filter); AUTO picks this one (ABI >= 3) */
+                                 directly in FP64 (no pre-filter) (ABI >= 3) */
 } yawhip_kernel;
 
 typedef struct yawhip_ctx yawhip_ctx;
@@ -95,7 +96,7 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
  *                       otherwise the cross-correlation path falls back to ordinary (job, bin) items.
  *   "seg_strips"        binned x binned counts use the per-(patch, bin) strip layouts of dense catalogues (default 1)
- *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 40)
+ *   "seg_strips_min_run" mean objects per (patch, bin, strip) run of the lane-side catalogue from which they are used (default 16)
  *   "debug_no_hits"     diagnostics: the pre-filter rejects everything (times the filter alone; wrong counts)
  *   "auto_orient"       1 (default): every job runs on the strip layouts of the orientation (sort axis u, strips along v,
  *                       dropped axis w) that suits its two patches -- w pointing at them; layouts of further

@@ -123,12 +123,11 @@ def test_config4_weighted_autocorrelation_with_10x_randoms(golden):
     ld = data.build_trees(config.binning.edges, closed=config.binning.closed)
     lr = rand.build_trees(config.binning.edges, closed=config.binning.closed)
     links, t, combine = _setup(config, data, rand)
-    modes = {}
+    modes, kernels = {}, {}
     for name, l1, l2, auto in (("DD", ld, ld, True), ("DR", ld, lr, False), ("RR", lr, lr, True)):
         jobs = links.get_patch_pairs(data, None if auto else rand)
         fine, st = engine.count_fine(l1, l2, jobs, t)
-        modes[name] = st.layout_mode
-        assert st.kernel_used == _lib.KERNEL_BAND
+        modes[name], kernels[name] = st.layout_mode, st.kernel_used
         exp_tot = np.array(g["pairs_per_scale_bin"][name])
         np.testing.assert_allclose(_per_scale_bin(combine, fine, jobs, auto), exp_tot, rtol=1e-10, atol=0, err_msg=name)
         again, _ = engine.count_fine(l1, l2, jobs, t)
@@ -148,7 +147,10 @@ def test_config4_weighted_autocorrelation_with_10x_randoms(golden):
             d1 = engine.device_catalog(l1, ctx)
             counts, _, _ = _lib.count_pairs(ctx, d1, d1, jobs[jobs[:, 0] == jobs[:, 1]][:8], t, want_counts=True, want_sums=False)
             assert np.all(counts % 2 == 0) and counts.sum() > 0
-    assert modes == {"DD": 0, "DR": 3, "RR": 3} or modes["RR"] == 3
+    # every count runs on the per-(patch, bin) strip layouts; AUTO takes the band kernel where the streamed runs are
+    # dense (the randoms) and the sweep kernel where they hold a few dozen objects (the data)
+    assert modes == {"DD": 3, "DR": 3, "RR": 3}
+    assert kernels["RR"] == _lib.KERNEL_BAND and kernels["DD"] == kernels["DR"] == _lib.KERNEL_SWEEP
     # the public entry point end to end (catalogues resident): Landy-Szalay amplitudes are finite and small
     (cf,) = yaw.autocorrelate(config, data, rand)
     assert cf.dd is not None and cf.dr is not None and cf.rr is not None

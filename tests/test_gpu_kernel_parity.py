@@ -523,7 +523,7 @@ def test_segment_strip_layout_path(ctx, weights):
                     # (a weighted call that also returns counts runs the kernel twice)
                     assert work.sum() * (2 if weights == "ww" else 1) == evaluated[(micro, a is c1, seg, 4)]
     finally:
-        ctx.set_option("seg_strips_min_run", 40)
+        ctx.set_option("seg_strips_min_run", 16)
         ctx.set_option("seg_strips", 1)
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("tile_r", 0)
@@ -605,7 +605,7 @@ def test_borderline_pairs_on_the_strip_paths(ctx, kernel, layout, micro):
             assert np.array_equal(counts, exp)
     finally:
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
-        ctx.set_option("seg_strips_min_run", 40)
+        ctx.set_option("seg_strips_min_run", 16)
         ctx.set_option("tile_r", 0)
 
 

@@ -58,7 +58,8 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
-constexpr int SEG_STRIPS_MIN_RUN = 40;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
+constexpr int SEG_STRIPS_MIN_RUN = 16;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
+constexpr int BAND_MIN_STREAM_RUN = 64;  // AUTO: mean objects per run of the streamed side from which the band kernel is used
 constexpr int64_t SYNC_GRID_MIN_ITEMS = 400000;  // potential items from which the count grid is sized exactly (one host sync)
 constexpr int MAX_STRIP_REACH = 12;  // strip pairing is used while sqrt(t_max) <= 12 grid spacings
 constexpr int COUNT_FLUSH_MASK = (1 << 13) - 1;  // k_count: stages between flushes of the 32-bit LDS counters (see there)
@@ -961,7 +962,9 @@ __device__ __forceinline__ __attribute__((address_space(3))) void *lds_ptr(unsig
 __device__ __forceinline__ double lds_f64(unsigned addr) { return *(const __attribute__((address_space(3))) double *)(size_t)addr; }
 __device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribute__((address_space(3))) int *)(size_t)addr; }
 
-template <int R, bool WEIGHTED, bool NF1, bool MERGED, bool UNI>
+// NE: edges per bin known at compile time (2: one fine bin; 3, 4: edges in registers when every bin -- or the item -- has one
+// row of them); 0: any number, edge table in LDS.
+template <int R, bool WEIGHTED, int NE, bool MERGED, bool UNI>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
@@ -969,7 +972,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                                                    double *__restrict__ partials,
                                                    unsigned long long *__restrict__ counters) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
-    constexpr bool NEED_THR = !NF1 || (MERGED && !UNI);  // edge table in LDS (else the two edges live in registers)
+    constexpr bool NF1 = NE == 2;
+    constexpr bool REG_EDGES = NE >= 2 && (!MERGED || UNI);  // the item's edges live in registers
+    constexpr bool NEED_THR = !REG_EDGES;                    // else: edge table in LDS
     constexpr int HB = WEIGHTED ? 3 : 2;                 // log2 of the bytes of a histogram cell
     __shared__ __attribute__((aligned(16))) unsigned char lds_fix[LDS_FIXED];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -1043,10 +1048,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                 aw[r] = (WEIGHTED && c2.w) ? (c2.w + it.a0)[ic] : 1.0;
             }
         }
-        double t_lo = 0.0, t_hi = 0.0;  // edges of the item's bin (or of every bin) in registers
-        if (!MERGED || UNI) {
-            t_lo = t[(int64_t)kfix * n_edges];
-            t_hi = t[(int64_t)kfix * n_edges + n_edges - 1];
+        double ed[NE >= 2 ? NE : 1];  // edges of the item's bin (or of every bin) in registers
+        if (REG_EDGES) {
+#pragma unroll
+            for (int q = 0; q < NE; ++q) ed[q] = t[(int64_t)kfix * n_edges + q];
         }
         if (NEED_THR)
             for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
@@ -1162,27 +1167,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     const double zz = dz * dz;
                     const double sxy2 = xx + yy;
                     const double sd = sxy2 + zz;
-                    const double *tk = thr + kb[r] * n_edges;  // edge table of the entry's bin
-                    const double e_lo = (!MERGED || UNI) ? t_lo : tk[0];
-                    const double e_hi = (!MERGED || UNI) ? t_hi : tk[n_edges - 1];
-                    const bool in = sd > e_lo && sd <= e_hi;
+                    bool in;
+                    int slot = kb[r] * nf;
+                    if constexpr (REG_EDGES) {
+                        in = sd > ed[0] && sd <= ed[NE - 1];
+                        if constexpr (NE >= 3) slot += (sd > ed[1]) ? 1 : 0;  // inner edges: t[c-1] < s <= t[c]
+                        if constexpr (NE >= 4) slot += (sd > ed[2]) ? 1 : 0;
+                    } else {
+                        const double *tk = thr + (MERGED ? kb[r] * n_edges : 0);  // edge row of the entry's bin
+                        in = sd > tk[0] && sd <= tk[n_edges - 1];
+                    }
                     if (NF1 && !MERGED && !WEIGHTED) {
                         cnt1 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(in));
-                    } else if (NF1 && !WEIGHTED) {
-                        // branch-free: a miss adds to the lane's own dummy cell (under a branch the compiler can no longer
-                        // count the LDS operations in flight)
-                        const unsigned cell = in ? ((unsigned)kb[r] << ksh) + a_cell : a_dummy;
-                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, 1u, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else if (REG_EDGES && !WEIGHTED) {
+                        // Branch-free: a miss adds to the lane's own dummy cell. (Under a branch the compiler can no longer
+                        // count the LDS operations in flight and drains them all before every evaluation.)
+                        const unsigned cell = in ? ((unsigned)slot << ksh) + a_cell : a_dummy;
+                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, 1u,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (in) {
-                        int slot = kb[r] * nf;
-                        if (!NF1) {
+                        if constexpr (!REG_EDGES) {
+                            const double *tk = thr + (MERGED ? kb[r] * n_edges : 0);
                             int c = 0;
                             for (int q = 0; q < n_edges; ++q) c += (sd > tk[q]) ? 1 : 0;
                             slot += c - 1;  // t[c-1] < s <= t[c], c >= 1 because s > t[0]
                         }
-                        // wave-private LDS histogram: integer adds are exact; float64 adds of ONE instruction that
-                        // hit the same slot are serialised by the LDS in a fixed lane order -> reproducible sums
+                        // The histogram belongs to this wave alone: integer adds are exact; float64 adds of ONE instruction
+                        // that hit the same cell are serialised by the LDS in a fixed lane order -> reproducible sums.
                         const unsigned cell = ((unsigned)slot << ksh) + a_cell;
                         if constexpr (WEIGHTED)
                             (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * bw[r],
@@ -2066,6 +2077,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         if (jobs[2 * j] < 0 || jobs[2 * j] >= c1->n_patches || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= c1->n_patches)
             return fail(YAWHIP_ERR_INVALID, "job %d has a patch id outside [0,%d)", j, c1->n_patches);
     if (kernel == YAWHIP_KERNEL_AUTO) kernel = ctx->default_kernel;
+    const bool auto_pick = kernel == YAWHIP_KERNEL_AUTO;  // BAND or SWEEP, whichever suits the layouts (decided below)
     if (kernel == YAWHIP_KERNEL_AUTO) kernel = YAWHIP_KERNEL_BAND;
     if (kernel < YAWHIP_KERNEL_EXACT || kernel > YAWHIP_KERNEL_BAND)
         return fail(YAWHIP_ERR_INVALID, "unknown kernel id %d", kernel);
@@ -2075,7 +2087,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     // the window search compares the sorted coordinate of both sides: the axes must agree
     if ((kernel == YAWHIP_KERNEL_SWEEP || kernel == YAWHIP_KERNEL_BAND) && c1->axis != c2->axis)
         kernel = unit ? YAWHIP_KERNEL_FILTER : YAWHIP_KERNEL_EXACT;
-    const bool band = kernel == YAWHIP_KERNEL_BAND;  // exact FP64 on per-object bands: needs no unit vectors
+    bool band = kernel == YAWHIP_KERNEL_BAND;  // exact FP64 on per-object bands: needs no unit vectors
     const bool sweep = kernel == YAWHIP_KERNEL_SWEEP || band;
     const bool filter = unit && kernel != YAWHIP_KERNEL_EXACT;
 
@@ -2145,6 +2157,24 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             L2[o] = mode == 3 ? &c2->seg[o] : &c2->strips[o];
         }
     }
+    if (auto_pick && band && unit) {
+        // The band kernel decides every entry of a per-object band in FP64: unbeatable while a band is a handful of
+        // entries of which half are pairs (strip layouts of dense catalogues). Without strips a band is the whole
+        // u-window of a segment, nearly all of it far away along v -- the FP32 pre-filter of the sweep kernel is made
+        // for that; and when the streamed runs hold a few dozen objects (sparse data against dense randoms) a work item
+        // is all fixed cost, which the sweep kernel has less of (measured on config #4).
+        bool use_sweep = mode == 0;
+        if (!use_sweep) {
+            int64_t runs1 = 1;
+            for (int o = 0; o < 3; ++o)
+                if (L1[o]) runs1 = std::max(runs1, L1[o]->h_vbase[(size_t)L1[o]->n_groups]);
+            use_sweep = c1->n / runs1 < BAND_MIN_STREAM_RUN;
+        }
+        if (use_sweep) {
+            kernel = YAWHIP_KERNEL_SWEEP;
+            band = false;
+        }
+    }
     int R = ctx->tile_r;
     if (R == 0) {
         int64_t max_seg = 0;
@@ -2173,7 +2203,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     for (int k = 1; k < n_bins && uniform_t; ++k)
         uniform_t = memcmp(t, t + (size_t)k * n_edges, sizeof(double) * n_edges) == 0;
     const int hp_shift = lean_bins * nf <= 32 ? 2 : 0;  // few histogram slots: four copies, lanes spread over them
-    const bool band_thr = nf != 1 || (merged && !uniform_t);
+    const int band_ne = (!merged || uniform_t) && n_edges <= 4 ? n_edges : (nf == 1 ? 2 : 0);  // compile-time edge count of k_count_band
+    const bool band_thr = !(band_ne >= 2 && (!merged || uniform_t));
     const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift);
     if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
@@ -2440,12 +2471,13 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         else if (uniform_t) YAW_LAUNCH_BAND_R(WW, NN, true, true);                                                    \
         else YAW_LAUNCH_BAND_R(WW, NN, true, false);                                                                  \
     } while (0)
-            const bool nf1 = nf == 1;
-            if (wgt) {
-                if (nf1) YAW_LAUNCH_BAND_M(true, true); else YAW_LAUNCH_BAND_M(true, false);
-            } else {
-                if (nf1) YAW_LAUNCH_BAND_M(false, true); else YAW_LAUNCH_BAND_M(false, false);
-            }
+#define YAW_LAUNCH_BAND_N(WW)                                                                                         \
+    do {                                                                                                              \
+        if (band_ne == 2) YAW_LAUNCH_BAND_M(WW, 2); else if (band_ne == 3) YAW_LAUNCH_BAND_M(WW, 3);                  \
+        else if (band_ne == 4) YAW_LAUNCH_BAND_M(WW, 4); else YAW_LAUNCH_BAND_M(WW, 0);                               \
+    } while (0)
+            if (wgt) YAW_LAUNCH_BAND_N(true); else YAW_LAUNCH_BAND_N(false);
+#undef YAW_LAUNCH_BAND_N
 #undef YAW_LAUNCH_BAND_M
 #undef YAW_LAUNCH_BAND_R
 #undef YAW_LAUNCH_BAND
