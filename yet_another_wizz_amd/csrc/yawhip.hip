@@ -1035,15 +1035,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         };
         stage_in(0, (int)(nb_total < BCAP ? nb_total : BCAP));
         // lane objects and thresholds while the stage is in flight
+        // A lane holds R NEIGHBOURING objects of the (u-sorted) tile: their bands overlap almost completely, so the lane
+        // walks their union once -- one read of an entry serves R evaluations, two searches serve R objects.
         double ax[R], ay[R], az[R], aw[R];
-        bool ok[R];
+        int n_own = (int)it.na - lane * R;  // objects of this lane (<= 0: none)
+        n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
         {
             const gf64p px = c2.x + it.a0, py = c2.y + it.a0, pz = c2.z + it.a0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const unsigned i = (unsigned)(r * 64 + lane);
-                ok[r] = i < (unsigned)it.na;
-                const unsigned ic = ok[r] ? i : 0u;
+                const bool have = r < n_own;
+                const unsigned ic = have ? (unsigned)(lane * R + r) : 0u;
                 ax[r] = px[ic]; ay[r] = py[ic]; az[r] = pz[ic];
                 aw[r] = (WEIGHTED && c2.w) ? (c2.w + it.a0)[ic] : 1.0;
             }
@@ -1056,13 +1058,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (NEED_THR)
             for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
         for (int e = lane; e < nslots * hp; e += 64) hist[e] = HistT(0);
-        double klo[R], khi[R];
+        // the lane's band: from the first object's lower to the last object's upper bound (the tile is sorted along u)
+        double klo, khi;
+        {
+            const int last_r = n_own > 0 ? n_own - 1 : 0;
+            double u_first = c2.axis == 0 ? ax[0] : (c2.axis == 1 ? ay[0] : az[0]), u_last = u_first;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double ua = c2.axis == 0 ? ax[r] : (c2.axis == 1 ? ay[r] : az[r]);
-            klo[r] = ua - rwin;
-            khi[r] = ua + rwin;
+            for (int r = 1; r < R; ++r)
+                if (r == last_r) u_last = c2.axis == 0 ? ax[r] : (c2.axis == 1 ? ay[r] : az[r]);
+            klo = u_first - rwin;
+            khi = u_last + rwin;
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r)  // slots without an object sit beyond every edge of every entry
+            if (r >= n_own) { ax[r] = PAD_COORD; ay[r] = PAD_COORD; az[r] = PAD_COORD; aw[r] = 0.0; }
         unsigned int cnt1 = 0;             // NF1 && !MERGED: the item's only counter lives in a register
         unsigned int nev = 0;              // band entries this lane evaluated
         unsigned stage_no = 0;
@@ -1104,31 +1113,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (WEIGHTED && !c1.w)
                 for (int e = lane; e < n; e += 64) sw[e] = 1.0;
             __syncthreads();
-            // band of every lane object inside this stage: [lo, hi) = entries with klo <= key <= khi
-            int lo[R], hi[R];
+            // band of the lane inside this stage: [lo, hi) = entries with klo <= key <= khi
+            int lo = 0, hi = 0;
             const int top = 1 << (31 - __builtin_clz(n));  // largest power of two <= n
-#pragma unroll
-            for (int r = 0; r < R; ++r) lo[r] = hi[r] = 0;
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
             for (int step = 0; step > 0; step >>= 1) {  // diagnostics: no search either
 #else
             for (int step = top; step > 0; step >>= 1) {
 #endif
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int pl = lo[r] + step, ph = hi[r] + step;
-                    const double kl = skey[(pl < n ? pl : n) - 1], kh = skey[(ph < n ? ph : n) - 1];
-                    lo[r] = (pl <= n && kl < klo[r]) ? pl : lo[r];    // entries [0, lo) have key <  klo
-                    hi[r] = (ph <= n && kh <= khi[r]) ? ph : hi[r];   // entries [0, hi) have key <= khi
-                }
+                const int pl = lo + step, ph = hi + step;
+                const double kl = skey[(pl < n ? pl : n) - 1], kh = skey[(ph < n ? ph : n) - 1];
+                lo = (pl <= n && kl < klo) ? pl : lo;    // entries [0, lo) have key <  klo
+                hi = (ph <= n && kh <= khi) ? ph : hi;   // entries [0, hi) have key <= khi
             }
-            int len = 0;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (!ok[r]) lo[r] = hi[r] = n;  // lanes without an object walk the sentinel
-                len = max(len, hi[r] - lo[r]);
-                nev += (unsigned int)(hi[r] - lo[r]);
-            }
+            if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
+            int len = hi - lo;
+            nev += (unsigned int)(len * n_own);
             for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1
             const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
@@ -1136,29 +1136,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const int steps = __builtin_amdgcn_readfirstlane(len);  // the longest band of the wave: uniform trip count
 #endif
 
-            // Walk the bands, one entry per lane object and trip. A lane whose band has ended moves on through the window
-            // (entries beyond the band have |du| > r_win, hence s > every upper edge: they fail the predicate by
-            // themselves) and parks on the sentinel. Occupancy, not a software pipeline inside the wave, covers the LDS
+            // Walk the band, one entry per trip, evaluated against the lane's R objects. A lane whose band has ended moves
+            // on through the window (entries beyond a band have |du| > r_win, hence s > every upper edge: they fail the
+            // predicate by themselves, as do the band's entries that lie outside the narrower band of one of the R
+            // objects) and parks on the sentinel. Occupancy, not a software pipeline inside the wave, covers the LDS
             // latency of a trip (the pipeline would cost the registers that occupancy needs).
-            unsigned cur[R];  // LDS address of the next entry's x; y, z and the bin id follow at fixed distances
+            unsigned cur = a_sx + ((unsigned)lo << 3);  // LDS address of the next entry's x; y, z, bin id at fixed distances
             const unsigned last = a_sx + ((unsigned)n << 3);
-#pragma unroll
-            for (int r = 0; r < R; ++r) cur[r] = a_sx + ((unsigned)lo[r] << 3);
             for (int s = 0; s < steps; ++s) {
-                double bx[R], by[R], bz[R], bw[R];
-                int kb[R];
+                const unsigned a8 = cur < last ? cur : last;
+                cur += 8;
+                const double ex = lds_f64(a8);
+                const double ey = lds_f64(a8 + (LDS_Y - LDS_X));
+                const double ez = lds_f64(a8 + (LDS_Z - LDS_X));
+                const double ew = WEIGHTED ? lds_f64(a8 - a_sx + a_sw) : 1.0;
+                const int ek = MERGED ? lds_i32(((a8 - a_sx) >> 1) + a_sx + (LDS_K - LDS_X)) : 0;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const unsigned a8 = cur[r] < last ? cur[r] : last;
-                    cur[r] += 8;
-                    bx[r] = lds_f64(a8);
-                    by[r] = lds_f64(a8 + (LDS_Y - LDS_X));
-                    bz[r] = lds_f64(a8 + (LDS_Z - LDS_X));
-                    bw[r] = WEIGHTED ? lds_f64(a8 - a_sx + a_sw) : 1.0;
-                    kb[r] = MERGED ? lds_i32(((a8 - a_sx) >> 1) + a_sx + (LDS_K - LDS_X)) : 0;
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
+                    double bx[R], by[R], bz[R], bw[R];
+                    int kb[R];
+                    bx[r] = ex; by[r] = ey; bz[r] = ez; bw[r] = ew; kb[r] = ek;
                     const double dx = ax[r] - bx[r];
                     const double dy = ay[r] - by[r];
                     const double dz = az[r] - bz[r];
