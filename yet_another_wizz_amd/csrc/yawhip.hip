@@ -945,16 +945,31 @@ constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane
 //   * two ds_read_b64 less than 2041 bytes, or a multiple of 512 bytes, apart would be fused into ds_read2_b64 /
 //     ds_read2st64_b64, which take twice their LDS cycles.
 // Weights, edge tables and histograms too large for the gaps follow in dynamic LDS.
-constexpr int BCOL = (BCAP + 2) * 8;      // bytes of a float64 column (BCAP entries + sentinel, 16-byte multiple): 1296
-constexpr int BKCOL = (BCAP + 4) * 4;     // bytes of the bin-id column: 656
-constexpr int LDS_X = 0, LDS_K = LDS_X + BCOL, LDS_Y = 2064, LDS_H = LDS_Y + BCOL, LDS_Z = 4128, LDS_FIXED = LDS_Z + BCOL;
-constexpr int LDS_H_BYTES = LDS_Z - LDS_H - 256;  // room of the small histogram (the 64 dummy cells follow it): 496
-static_assert(LDS_K + BKCOL <= LDS_Y && LDS_H_BYTES >= 480, "band LDS image");
-__host__ __device__ inline bool band_small_hist(bool weighted, int nslots, int hp) { return (size_t)nslots * hp * (weighted ? 8 : 4) <= (size_t)LDS_H_BYTES; }
+constexpr int band_apart(int at_least, int from1, int from2) {  // next 16-byte aligned offset >= at_least that is no multiple of
+    int v = (at_least + 15) & ~15;                              // 512 bytes away from from1 and from2 (and >= 2048 away: caller)
+    while ((v - from1) % 512 == 0 || (v - from2) % 512 == 0) v += 16;
+    return v;
+}
+constexpr int band_max(int a, int b) { return a > b ? a : b; }
+template <int CAP>
+struct BandLds {  // byte offsets inside the static LDS image of a band workgroup whose stage holds CAP entries
+    static constexpr int COL = (CAP + 2) * 8;   // a float64 column: CAP entries + sentinel, 16-byte multiple
+    static constexpr int KCOL = (CAP + 4) * 4;  // the bin-id column
+    static constexpr int X = 0, K = COL;
+    static constexpr int Y = band_apart(band_max(K + KCOL, X + 2048), X, X);
+    static constexpr int H = Y + COL;           // small histogram (H_BYTES), then 64 dummy cells
+    static constexpr int H_BYTES = 512;
+    static constexpr int Z = band_apart(band_max(H + H_BYTES + 256, Y + 2048), Y, X);
+    static constexpr int FIXED = Z + COL;
+};
+static_assert(BandLds<160>::Y == 2064 && BandLds<160>::Z == 4128 && BandLds<160>::FIXED == 5424, "band LDS image");
+constexpr int band_cap(int r) { return r >= 4 ? 288 : BCAP; }  // stage capacity: the window of a 64 r-object tile plus its bands
+inline int band_lds_fixed(int r) { return r >= 4 ? BandLds<288>::FIXED : BandLds<BCAP>::FIXED; }
+__host__ __device__ inline bool band_small_hist(bool weighted, int nslots, int hp) { return (size_t)nslots * hp * (weighted ? 8 : 4) <= 512; }
 // dynamic LDS bytes of a band workgroup (host and device agree through this one function)
-__host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp) {
+__host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp, int cap) {
     const int nslots = nkb * (n_edges - 1);
-    return (weighted ? (size_t)BCOL : 0) + (need_thr ? (size_t)nkb * n_edges * sizeof(double) : 0) +
+    return (weighted ? (size_t)(cap + 2) * 8 : 0) + (need_thr ? (size_t)nkb * n_edges * sizeof(double) : 0) +
            (band_small_hist(weighted, nslots, hp) ? 0 : (size_t)nslots * hp * (weighted ? 8 : 4)) + 16;
 }
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -965,7 +980,7 @@ __device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribu
 // NE: edges per bin known at compile time (2: one fine bin; 3, 4: edges in registers when every bin -- or the item -- has one
 // row of them); 0: any number, edge table in LDS.
 template <int R, bool WEIGHTED, int NE, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
                                                    unsigned long long *__restrict__ out_counts,
@@ -976,7 +991,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     constexpr bool REG_EDGES = NE >= 2 && (!MERGED || UNI);  // the item's edges live in registers
     constexpr bool NEED_THR = !REG_EDGES;                    // else: edge table in LDS
     constexpr int HB = WEIGHTED ? 3 : 2;                 // log2 of the bytes of a histogram cell
-    __shared__ __attribute__((aligned(16))) unsigned char lds_fix[LDS_FIXED];
+    constexpr int CAP = band_cap(R);
+    using L = BandLds<CAP>;
+    constexpr int LDS_X = L::X, LDS_K = L::K, LDS_Y = L::Y, LDS_H = L::H, LDS_Z = L::Z, LDS_H_BYTES = L::H_BYTES, BCOL = L::COL;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_fix[L::FIXED];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
     const int nkb = MERGED ? n_bins : 1;  // bins one item can add to
     const int nf = NF1 ? 1 : n_edges - 1;
@@ -1021,7 +1039,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         auto stage_in = [&](int64_t first, int n) {
             const gf64p gx = c1.x + b0 + first, gy = c1.y + b0 + first, gz = c1.z + b0 + first;
 #pragma unroll
-            for (int c = 0; c < (BCAP + 127) / 128; ++c) {
+            for (int c = 0; c < (CAP + 127) / 128; ++c) {
                 const unsigned e = (unsigned)(c * 128 + 2 * lane);
                 if (e < (unsigned)n) {
                     __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_sx + c * 1024), 16, 0, 0);
@@ -1030,10 +1048,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
                     if (WEIGHTED && c1.w) __builtin_amdgcn_global_load_lds(c1.w + b0 + first + e, lds_ptr(a_sw + c * 1024), 16, 0, 0);
                 }
             }
-            if (MERGED && (unsigned)(4 * lane) < (unsigned)n)
-                __builtin_amdgcn_global_load_lds(c1.k + b0 + first + (unsigned)(4 * lane), lds_ptr(a_sx + (LDS_K - LDS_X)), 16, 0, 0);
+            if (MERGED) {
+#pragma unroll
+                for (int c = 0; c < (CAP + 255) / 256; ++c) {
+                    const unsigned e = (unsigned)(c * 256 + 4 * lane);
+                    if (e < (unsigned)n)
+                        __builtin_amdgcn_global_load_lds(c1.k + b0 + first + e, lds_ptr(a_sx + (LDS_K - LDS_X) + c * 1024), 16, 0, 0);
+                }
+            }
         };
-        stage_in(0, (int)(nb_total < BCAP ? nb_total : BCAP));
+        stage_in(0, (int)(nb_total < CAP ? nb_total : CAP));
         // lane objects and thresholds while the stage is in flight
         // A lane holds R NEIGHBOURING objects of the (u-sorted) tile: their bands overlap almost completely, so the lane
         // walks their union once -- one read of an entry serves R evaluations, two searches serve R objects.
@@ -1098,8 +1122,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             b0 = win == 1 ? it.b0[1] : it.b0[2];
             nb_total = win == 1 ? it.nb[1] : it.nb[2];
         }
-        for (int64_t st0 = 0; st0 < nb_total; st0 += BCAP, ++stage_no) {
-            const int n = (int)(nb_total - st0 < BCAP ? nb_total - st0 : BCAP);
+        for (int64_t st0 = 0; st0 < nb_total; st0 += CAP, ++stage_no) {
+            const int n = (int)(nb_total - st0 < CAP ? nb_total - st0 : CAP);
             if (st0 > 0 || win > 0) {
                 __syncthreads();  // every lane is done with the previous stage
                 stage_in(st0, n);
@@ -2189,8 +2213,28 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         const int wg = lean ? MWG : WG;
         R = max_seg >= 8 * wg * 4 ? 4 : (max_seg >= 4 * wg * 2 ? 2 : 1);
         if (strip_items && R > 2) R = 2;  // on strip runs two objects per lane beat four at every size measured (10M: 2.25 / 2.5 ms, 50M: 68 / 72 ms)
+        if (band && strip_items) {
+            // band kernel: a lane walks the union of the bands of its R neighbouring objects, R - 1 entries longer than
+            // one band. Four objects per lane pay once a band holds many entries (measured: 14 entries 0.57 / 0.72 ms,
+            // 55 entries 6.35 / 6.49 ms, 175 entries 39.9 / 33.8 ms for R = 2 / 4). Expected band length = 2 r_win x
+            // (objects of a streamed run per unit of u).
+            int64_t runs1 = 1;
+            for (int o = 0; o < 3; ++o)
+                if (L1[o]) runs1 = std::max(runs1, L1[o]->h_vbase[(size_t)L1[o]->n_groups]);
+            double extent = 0.0;
+            int n_ext = 0;
+            for (int p = 0; p < c1->n_patches; ++p) {
+                const double *b = &c1->h_box[(size_t)6 * p];
+                double widest = 0.0;
+                for (int a = 0; a < 3; ++a) widest = std::max(widest, b[3 + a] - b[a]);
+                if (widest > 0.0) { extent += widest; ++n_ext; }
+            }
+            extent = n_ext ? extent / n_ext : 1.0;
+            const double band_len = 2.0 * rwin_max * ((double)c1->n / (double)runs1) / std::max(extent, 1e-6);
+            R = band_len >= 80.0 ? 4 : 2;
+        }
     }
-    if (band && R > 2) R = 2;  // the band kernel keeps its lane objects in float64 registers: one or two per lane
+    if (band && R == 0) R = 2;
     const int64_t tile = (int64_t)(lean ? MWG : WG) * R;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
@@ -2202,7 +2246,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const int hp_shift = lean_bins * nf <= 32 ? 2 : 0;  // few histogram slots: four copies, lanes spread over them
     const int band_ne = (!merged || uniform_t) && n_edges <= 4 ? n_edges : (nf == 1 ? 2 : 0);  // compile-time edge count of k_count_band
     const bool band_thr = !(band_ne >= 2 && (!merged || uniform_t));
-    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift);
+    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, band_cap(R));
+    const size_t LDS_FIXED = (size_t)band_lds_fixed(R);
     if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
 
@@ -2460,7 +2505,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     } while (0)
 #define YAW_LAUNCH_BAND_R(WW, NN, MM, UU)                                                                             \
     do {                                                                                                              \
-        if (R == 1) YAW_LAUNCH_BAND(1, WW, NN, MM, UU); else YAW_LAUNCH_BAND(2, WW, NN, MM, UU);                      \
+        if (R == 1) YAW_LAUNCH_BAND(1, WW, NN, MM, UU); else if (R == 2) YAW_LAUNCH_BAND(2, WW, NN, MM, UU);          \
+        else YAW_LAUNCH_BAND(4, WW, NN, MM, UU);                                                                      \
     } while (0)
 #define YAW_LAUNCH_BAND_M(WW, NN)                                                                                     \
     do {                                                                                                              \
