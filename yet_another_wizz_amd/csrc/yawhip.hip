@@ -140,6 +140,7 @@ struct DevTab {
     gi32p k;                   // bin id per object (merged cross-correlation layouts), else null
     gi64p off;                 // run offsets [V+1] (strip layouts) or segment offsets
     gi64p vbase, slo, tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
+    gi32p tile_run;            // strip layouts: run of every lane tile
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
@@ -155,8 +156,12 @@ __device__ __forceinline__ gf64p tab_key(const DevTab &t) { return t.axis == 0 ?
 //                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
 //                  dropped; survivors are appended with one atomic per workgroup (order is irrelevant).
 // ------------------------------------------------------------------------------------------------
-constexpr int BUILD_WG = 1024;  // threads per workgroup of the item builders
-constexpr int BUILD_PREFIX_LDS = 4096;  // job tables up to this many entries are searched in LDS by the strip builder
+constexpr int BUILD_WG = 1024;       // most threads per workgroup of the item builders
+// Builder workgroups: one atomic per workgroup appends its items, so few large workgroups suit long lists (16 k atomics on
+// the one counter cost 0.15 ms at 4 M potential items), but 1024 threads make 300 workgroups for 256 CUs at the headline
+// and half the chip waits for the CUs that got two (+0.07 ms): 256 threads while that keeps the atomics below 4096.
+inline int build_wg_for(int64_t n_pot) { return n_pot / 256 <= 4096 ? 256 : BUILD_WG; }
+constexpr int BUILD_PREFIX_LDS = 1024;  // job tables up to this many entries are searched in LDS by the strip builder (8 KB: no occupancy cost)
 
 // Append the kept items of a builder workgroup to the item list and add its evaluated-pair total: ONE atomic
 // per workgroup on each of the two counters. (They are single hot addresses -- with an atomic per wave the
@@ -177,7 +182,7 @@ __device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned
     if (threadIdx.x == 0) {
         unsigned int total = 0;
         unsigned long long wsum = 0;
-        for (int wv = 0; wv < BUILD_WG / 64; ++wv) {
+        for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) {
             const unsigned int c = s_cnt[wv];
             s_cnt[wv] = total;  // exclusive prefix
             total += c;
@@ -292,16 +297,12 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const int64_t r_lo = c2.vbase[q] + job_runs[3 * job], r_hi = r_lo + job_runs[3 * job + 1];
         const int64_t t_lo = c2.tiles[r_lo];
         const int64_t local = pot - (prefix_in_lds ? s_prefix[job] : prefix[job]);
-        int64_t l = r_lo, h = r_hi;  // run = largest r in [r_lo, r_hi) with ng * tiles-before-r <= local (skips empty runs)
-        while (h - l > 1) {
-            const int64_t m = (l + h) >> 1;
-            if ((c2.tiles[m] - t_lo) * ng <= local) l = m; else h = m;
-        }
-        const int64_t r2 = l;
-        const int64_t run_tiles = c2.tiles[r2 + 1] - c2.tiles[r2];
-        const int64_t in_run = local - (c2.tiles[r2] - t_lo) * ng;
-        const int g = (int)(in_run / run_tiles);
-        const int64_t target = c2.tiles[r2] + in_run % run_tiles;
+        // potential items of a job in the order (lane tile, group of neighbour offsets); the run of a tile comes from the
+        // layout's tile -> run table (one load; a search over the tile prefix was a third of this kernel's dependent loads)
+        const int g = (int)(local % ng);
+        const int64_t target = t_lo + local / ng;
+        const int64_t r2 = c2.tile_run[target];
+        int64_t l, h;
         const int64_t a_seg1 = c2.off[r2 + 1];
         const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
         const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
@@ -1288,8 +1289,9 @@ __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, do
 }
 
 inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
-                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, int axis) {
-    return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles, axis, 0};
+                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const int32_t *tile_run, int axis) {
+    return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
+                  (gi32p)tile_run, axis, 0};
 }
 
 template <typename T>
@@ -1323,7 +1325,7 @@ struct Arena {
         if (n <= cap) return hipSuccess;
         release();
         const size_t want = n + n / 4 + 4096;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&h), want, hipHostMallocPortable);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d), want);
         if (e == hipSuccess) cap = want; else release();
         return e;
@@ -1397,14 +1399,17 @@ struct StripLayout {
     std::vector<int64_t> h_slo;       // [G]   global strip index of a group's first run
     std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
     int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
+    int32_t *d_tile_run[3] = {nullptr, nullptr, nullptr};  // [tiles] run of every lane tile (inverse of the tile prefix)
     int64_t n_groups = 0;
     int64_t device_bytes = 0;
     void release() {
         for (void *q : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)off, (void *)d_vbase, (void *)d_slo,
-                        (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2]})
+                        (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_run[0], (void *)d_tile_run[1],
+                        (void *)d_tile_run[2]})
             if (q) (void)hipFree(q);
         x = y = z = w = nullptr; k = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
+        d_tile_run[0] = d_tile_run[1] = d_tile_run[2] = nullptr;
         built = false;
     }
 };
@@ -1748,6 +1753,15 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
         L.h_tiles[ri].assign((size_t)n_runs + 1, 0);
         for (int64_t r = 0; r < n_runs; ++r)
             L.h_tiles[ri][(size_t)r + 1] = L.h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
+        {  // run of every tile: the item builder decodes a potential item with one load instead of a search over the prefix
+            const int64_t n_tiles = L.h_tiles[ri][(size_t)n_runs];
+            std::vector<int32_t> tile_run((size_t)std::max<int64_t>(n_tiles, 1));
+            for (int64_t r = 0; r < n_runs; ++r)
+                for (int64_t tl = L.h_tiles[ri][(size_t)r]; tl < L.h_tiles[ri][(size_t)r + 1]; ++tl) tile_run[(size_t)tl] = (int32_t)r;
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tile_run[ri]), tile_run.size() * sizeof(int32_t));
+            if (e == hipSuccess)
+                e = hipMemcpy(L.d_tile_run[ri], tile_run.data(), tile_run.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
         if (e == hipSuccess)
             e = hipMemcpyAsync(L.d_tiles[ri], L.h_tiles[ri].data(), (size_t)(n_runs + 1) * sizeof(int64_t),
@@ -2355,12 +2369,14 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         for (int o = 0; o < 3; ++o) {
             if (!L1[o]) continue;
             const StripLayout &a = *L1[o], &b = *L2[o];
-            h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx], o);
-            h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx], o);
+            h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx],
+                                 a.d_tile_run[tile_idx], o);
+            h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx],
+                                     b.d_tile_run[tile_idx], o);
         }
     } else {
-        h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, c1->axis);
-        h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, c2->axis);
+        h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, c1->axis);
+        h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, nullptr, c2->axis);
     }
     // the tables of the call, packed into the pinned staging buffer and sent with one copy
     const size_t n_jobtab = strip_items ? (size_t)5 * n_sjobs : (size_t)2 * n_jobs;  // (p, q) pairs, then (first run, runs, orientation)
@@ -2418,17 +2434,18 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             HIP_TRY(hipMemsetAsync(ctx->d_kept.ptr, 0, (size_t)n_pot, ctx->stream));
             kept_flags = ctx->d_kept.ptr;
         }
-        const unsigned bgrid = (unsigned)((n_pot + BUILD_WG - 1) / BUILD_WG);
+        const int bwg = build_wg_for(n_pot);
+        const unsigned bgrid = (unsigned)((n_pot + bwg - 1) / bwg);
         if (strip_items)
-            hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, ctx->d_tabs.ptr,
+            hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(bwg), 0, ctx->stream, ctx->d_tabs.ptr,
                                ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, ctx->d_prefix.ptr, (int)n_sjobs, reach,
                                (int)tile, rwin_max, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
-            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
+            hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
                                ctx->d_rwin.ptr, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else
-            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(BUILD_WG), 0, ctx->stream, view_of(c1), view_of(c2),
+            hipLaunchKernelGGL(k_build_items<false>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile, ctx->d_rwin.ptr, n_pot,
                                ctx->d_items.ptr, ctx->d_ctr.ptr, nullptr);
         HIP_TRY(hipGetLastError());
