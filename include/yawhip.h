@@ -91,6 +91,8 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
 
 /* Tunables (all optional):
  *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)
+ *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 160, or 288 when a lane tile's window is
+ *                       expected to need more; 160; 288)
  *   "kernel"            default yawhip_kernel of yawhip_count_pairs(kernel = AUTO)
  *   "strip_width_micro" spacing, in 1e-6 chord units, of the strip grid of catalogues uploaded afterwards
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;

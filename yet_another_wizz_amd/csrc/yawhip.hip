@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         // wide as the largest separation): the lane tile is loaded once and its histogram flushed once for all of them.
         const int nd = 2 * reach + 1, ng = (nd + MAX_WIN - 1) / MAX_WIN;
         // runs of patch q whose grid index is within reach of some strip of patch p (host: job_runs)
-        const int64_t r_lo = c2.vbase[q] + job_runs[3 * job], r_hi = r_lo + job_runs[3 * job + 1];
+        const int64_t r_lo = c2.vbase[q] + job_runs[3 * job];
         const int64_t t_lo = c2.tiles[r_lo];
         const int64_t local = pot - (prefix_in_lds ? s_prefix[job] : prefix[job]);
         // potential items of a job in the order (lane tile, group of neighbour offsets); the run of a tile comes from the
@@ -302,7 +302,6 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const int g = (int)(local % ng);
         const int64_t target = t_lo + local / ng;
         const int64_t r2 = c2.tile_run[target];
-        int64_t l, h;
         const int64_t a_seg1 = c2.off[r2 + 1];
         const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
         const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
@@ -964,8 +963,13 @@ struct BandLds {  // byte offsets inside the static LDS image of a band workgrou
     static constexpr int FIXED = Z + COL;
 };
 static_assert(BandLds<160>::Y == 2064 && BandLds<160>::Z == 4128 && BandLds<160>::FIXED == 5424, "band LDS image");
-constexpr int band_cap(int r) { return r >= 4 ? 288 : BCAP; }  // stage capacity: the window of a 64 r-object tile plus its bands
-inline int band_lds_fixed(int r) { return r >= 4 ? BandLds<288>::FIXED : BandLds<BCAP>::FIXED; }
+// Stage capacities the band kernel is compiled for. A stage should hold the whole window of a lane tile (the tile's own
+// extent in streamed entries plus one band): a window cut into stages makes every stage wait for the longest clipped band
+// while the lanes whose bands lie in the other stage idle (50M x 50M, bands of 216 entries: 400 trips per 256 lane objects
+// with 288-entry stages against 219 in one stage).
+// (416-entry stages were measured too: never ahead of 288 -- 23.3 / 23.3 ms at 50M x 50M, 0.70 / 0.59 ms at the headline.)
+constexpr int BCAP_MID = 288;
+inline int band_lds_fixed(int cap) { return cap == BCAP_MID ? BandLds<BCAP_MID>::FIXED : BandLds<BCAP>::FIXED; }
 __host__ __device__ inline bool band_small_hist(bool weighted, int nslots, int hp) { return (size_t)nslots * hp * (weighted ? 8 : 4) <= 512; }
 // dynamic LDS bytes of a band workgroup (host and device agree through this one function)
 __host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp, int cap) {
@@ -980,7 +984,7 @@ __device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribu
 
 // NE: edges per bin known at compile time (2: one fine bin; 3, 4: edges in registers when every bin -- or the item -- has one
 // row of them); 0: any number, edge table in LDS.
-template <int R, bool WEIGHTED, int NE, bool MERGED, bool UNI>
+template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
 __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
@@ -992,7 +996,6 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
     constexpr bool REG_EDGES = NE >= 2 && (!MERGED || UNI);  // the item's edges live in registers
     constexpr bool NEED_THR = !REG_EDGES;                    // else: edge table in LDS
     constexpr int HB = WEIGHTED ? 3 : 2;                 // log2 of the bytes of a histogram cell
-    constexpr int CAP = band_cap(R);
     using L = BandLds<CAP>;
     constexpr int LDS_X = L::X, LDS_K = L::K, LDS_Y = L::Y, LDS_H = L::H, LDS_Z = L::Z, LDS_H_BYTES = L::H_BYTES, BCOL = L::COL;
     __shared__ __attribute__((aligned(16))) unsigned char lds_fix[L::FIXED];
@@ -1351,6 +1354,7 @@ struct yawhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
+    int band_cap = 0;        // entries per LDS stage of the band kernel: 0 = auto, 160, 288
     int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
@@ -1867,6 +1871,12 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->tile_r = (int)value;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "band_cap")) {
+        if (value != 0 && value != BCAP && value != BCAP_MID)
+            return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 160 or 288");
+        ctx->band_cap = (int)value;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "strip_width_micro")) {  // strip grid spacing in units of 1e-6 (0 = off)
         if (value != 0 && (value < 1000 || value > 2000000))
             return fail(YAWHIP_ERR_INVALID, "strip_width_micro must be 0 (off) or in [1e3, 2e6]");
@@ -2211,6 +2221,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         }
     }
     int R = ctx->tile_r;
+    double est_window = 0.0;  // band kernel: expected entries of one window
     if (R == 0) {
         int64_t max_seg = 0;
         if (strip_items) {  // lanes hold runs of a strip layout: their typical (mean) length decides
@@ -2228,27 +2239,38 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         R = max_seg >= 8 * wg * 4 ? 4 : (max_seg >= 4 * wg * 2 ? 2 : 1);
         if (strip_items && R > 2) R = 2;  // on strip runs two objects per lane beat four at every size measured (10M: 2.25 / 2.5 ms, 50M: 68 / 72 ms)
         if (band && strip_items) {
-            // band kernel: a lane walks the union of the bands of its R neighbouring objects, R - 1 entries longer than
-            // one band. Four objects per lane pay once a band holds many entries (measured: 14 entries 0.57 / 0.72 ms,
-            // 55 entries 6.35 / 6.49 ms, 175 entries 39.9 / 33.8 ms for R = 2 / 4). Expected band length = 2 r_win x
-            // (objects of a streamed run per unit of u).
-            int64_t runs1 = 1;
-            for (int o = 0; o < 3; ++o)
-                if (L1[o]) runs1 = std::max(runs1, L1[o]->h_vbase[(size_t)L1[o]->n_groups]);
-            double extent = 0.0;
-            int n_ext = 0;
-            for (int p = 0; p < c1->n_patches; ++p) {
-                const double *b = &c1->h_box[(size_t)6 * p];
-                double widest = 0.0;
-                for (int a = 0; a < 3; ++a) widest = std::max(widest, b[3 + a] - b[a]);
-                if (widest > 0.0) { extent += widest; ++n_ext; }
-            }
-            extent = n_ext ? extent / n_ext : 1.0;
-            const double band_len = 2.0 * rwin_max * ((double)c1->n / (double)runs1) / std::max(extent, 1e-6);
-            R = band_len >= 80.0 ? 4 : 2;
+            // band kernel: two neighbouring objects per lane at every density measured once a stage holds the whole
+            // window (four per lane: 0.66 / 0.59 ms at the headline, 33 / 24 ms at 50M x 50M, 7.0 / 5.7 ms for RR of
+            // config #4). Expected window = the tile's own extent in streamed entries + one band of
+            // 2 r_win x (streamed objects of a run per unit of u).
+            R = 2;
+            auto per_u = [](const auto *c, const StripLayout *const *Ls) {
+                int64_t runs = 1;
+                for (int o = 0; o < 3; ++o)
+                    if (Ls[o]) runs = std::max(runs, Ls[o]->h_vbase[(size_t)Ls[o]->n_groups]);
+                double extent = 0.0;
+                int n_ext = 0;
+                for (int p = 0; p < c->n_patches; ++p) {
+                    const double *b = &c->h_box[(size_t)6 * p];
+                    double widest = 0.0;
+                    for (int a = 0; a < 3; ++a) widest = std::max(widest, b[3 + a] - b[a]);
+                    if (widest > 0.0) { extent += widest; ++n_ext; }
+                }
+                extent = n_ext ? extent / n_ext : 1.0;
+                return ((double)c->n / (double)runs) / std::max(extent, 1e-6);
+            };
+            const double d1 = per_u(c1, L1), d2 = per_u(c2, L2);
+            est_window = 64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1;
         }
     }
     if (band && R == 0) R = 2;
+    // stage capacity of the band kernel: the smallest compiled one that holds a whole window (see BCAP_MID)
+    int cap = ctx->band_cap;
+    if (band && cap == 0) cap = R >= 4 || est_window > 0.95 * BCAP ? BCAP_MID : BCAP;
+    if (band) {  // combinations that are compiled
+        if (R == 1) cap = BCAP;
+        if (R == 4 && cap == BCAP) cap = BCAP_MID;
+    }
     const int64_t tile = (int64_t)(lean ? MWG : WG) * R;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
@@ -2260,8 +2282,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const int hp_shift = lean_bins * nf <= 32 ? 2 : 0;  // few histogram slots: four copies, lanes spread over them
     const int band_ne = (!merged || uniform_t) && n_edges <= 4 ? n_edges : (nf == 1 ? 2 : 0);  // compile-time edge count of k_count_band
     const bool band_thr = !(band_ne >= 2 && (!merged || uniform_t));
-    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, band_cap(R));
-    const size_t LDS_FIXED = (size_t)band_lds_fixed(R);
+    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, cap);
+    const size_t LDS_FIXED = (size_t)band_lds_fixed(cap);
     if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
 
@@ -2506,11 +2528,15 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // The strip builder keeps about one potential item in five, ordinary items are all kept.
         int64_t grid = strip_items && n_pot > 65536 ? n_pot / std::max(ctx->band_grid_div, 1) : n_pot;
         grid = std::min<int64_t>((grid + 7) & ~7ll, 1ll << 22);
-        const unsigned flush_mask = (1u << ctx->flush_log2) - 1u;
+        // 32-bit LDS counters: one stage adds at most 64 R x CAP to a cell, so flush at the latest every
+        // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 160-entry stages, 2^15 for four and 288)
+        int flush_log2 = ctx->flush_log2;
+        while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) > (1ull << 32)) --flush_log2;
+        const unsigned flush_mask = (1u << flush_log2) - 1u;
         auto launch_band = [&](bool wgt) -> hipError_t {
-#define YAW_LAUNCH_BAND(RR, WW, NN, MM, UU)                                                                           \
+#define YAW_LAUNCH_BAND(RR, CC, WW, NN, MM, UU)                                                                       \
     do {                                                                                                              \
-        auto kern = k_count_band<RR, WW, NN, MM, UU>;                                                                 \
+        auto kern = k_count_band<RR, CC, WW, NN, MM, UU>;                                                             \
         if (lds_band > 64 * 1024) {                                                                                   \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_band);           \
@@ -2522,8 +2548,10 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     } while (0)
 #define YAW_LAUNCH_BAND_R(WW, NN, MM, UU)                                                                             \
     do {                                                                                                              \
-        if (R == 1) YAW_LAUNCH_BAND(1, WW, NN, MM, UU); else if (R == 2) YAW_LAUNCH_BAND(2, WW, NN, MM, UU);          \
-        else YAW_LAUNCH_BAND(4, WW, NN, MM, UU);                                                                      \
+        if (R == 1) YAW_LAUNCH_BAND(1, BCAP, WW, NN, MM, UU);                                                         \
+        else if (R == 2 && cap == BCAP) YAW_LAUNCH_BAND(2, BCAP, WW, NN, MM, UU);                                     \
+        else if (R == 2) YAW_LAUNCH_BAND(2, BCAP_MID, WW, NN, MM, UU);                                                \
+        else YAW_LAUNCH_BAND(4, BCAP_MID, WW, NN, MM, UU);                                                            \
     } while (0)
 #define YAW_LAUNCH_BAND_M(WW, NN)                                                                                     \
     do {                                                                                                              \
