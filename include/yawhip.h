@@ -91,8 +91,8 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
 
 /* Tunables (all optional):
  *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)
- *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 160, or 288 when a lane tile's window is
- *                       expected to need more; 160; 288)
+ *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 192, or 288 when a lane tile's window is
+ *                       expected to need more; 192; 288)
  *   "kernel"            default yawhip_kernel of yawhip_count_pairs(kernel = AUTO)
  *   "strip_width_micro" spacing, in 1e-6 chord units, of the strip grid of catalogues uploaded afterwards
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
@@ -106,7 +106,7 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *   "slab_budget_bytes" weighted calls keep a slab of partial sums per potential work item; a job list that would need more
  *                       than this many bytes (default 2^30) is counted in pieces, one after the other (same results)
  *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every
- *                       2^value stages (default 17: 128 lane objects x 160 entries x 2^17 < 2^32; tests lower it) */
+ *                       2^value stages (default 17: 128 lane objects x 192 entries x 2^17 < 2^32; tests lower it) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
 
 /*
@@ -177,6 +177,20 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
  */
 int yawhip_assign_patches(yawhip_ctx *ctx, int64_t n, const double *x, const double *y, const double *z,
                           int32_t n_centers, const double *centers_xyz, int32_t *patch_out);
+
+/*
+ * Host-only helper of the ingest path (no device, no context): stable grouping of float64 columns by an integer key --
+ * what the reference does per chunk with groupby(patch_ids, chunk) (catalog/catalog.py:293, utils/misc.py:40-51) and
+ * groupby(bin_idx, chunk) (catalog/trees.py:413), i.e. np.argsort(kind="stable") + a gather per column, here as one
+ * threaded counting sort. Entries with key < 0 are dropped (objects outside the binning, trees.py:414).
+ *   keys       int32[n] or int64[n] (key_bytes = 4 | 8), every key < num_groups
+ *   in, out    n_cols pointers to float64[n] each; out[c] receives the kept entries of in[c], group after group, input
+ *              order inside a group; out[c] must not alias in[c]
+ *   sizes      int64[num_groups] entries per group (out)
+ *   n_threads  0 = one per core, at most 16
+ */
+int yawhip_host_group_columns(int64_t n, const void *keys, int32_t key_bytes, int64_t num_groups, int32_t n_cols,
+                              const double *const *in, double *const *out, int64_t *sizes, int32_t n_threads);
 
 /*
  * Evaluated pair distances per job, without counting anything: runs the item builder of yawhip_count_pairs for the

@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "yawhip_count_pairs",
     "yawhip_job_work",
     "yawhip_assign_patches",
+    "yawhip_host_group_columns",
 )
 
 
@@ -122,6 +123,10 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_assign_patches.argtypes = [_vp, ctypes.c_int64, _dp, _dp, _dp, ctypes.c_int32, _dp, _i32p]
     lib.yawhip_job_work.argtypes = [
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32, _i64p,
+    ]
+    lib.yawhip_host_group_columns.argtypes = [
+        ctypes.c_int64, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(_dp), ctypes.POINTER(_dp), _i64p,
+        ctypes.c_int32,
     ]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
@@ -277,6 +282,30 @@ def job_work(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, threshold
         "yawhip_job_work",
     )
     return work
+
+
+def group_columns(keys, num_groups: int, columns, n_threads: int = 0):
+    """``yawhip_host_group_columns``: stable grouping of float64 columns by integer key (host threads, no device).
+    Returns ``(grouped columns, sizes)``; entries with a negative key are dropped. Equivalent to
+    ``order = np.flatnonzero(keys >= 0)[np.argsort(keys[keys >= 0], kind="stable")]; [c[order] for c in columns]``."""
+    keys = np.ascontiguousarray(keys)
+    if keys.dtype not in (np.dtype(np.int32), np.dtype(np.int64)):
+        keys = keys.astype(np.int64)
+    cols = [_f64(c) for c in columns]
+    n = len(keys)
+    if any(len(c) != n for c in cols):
+        raise ValueError("columns and keys differ in length")
+    outs = [np.empty(n, dtype=np.float64) for _ in cols]
+    sizes = np.zeros(int(num_groups), dtype=np.int64)
+    arr = _dp * max(len(cols), 1)
+    _check(
+        load_library().yawhip_host_group_columns(
+            n, keys.ctypes.data_as(_vp), keys.dtype.itemsize, int(num_groups), len(cols),
+            arr(*[_ptr(c, _dp) for c in cols]), arr(*[_ptr(o, _dp) for o in outs]), _ptr(sizes, _i64p), int(n_threads)),
+        "yawhip_host_group_columns",
+    )
+    kept = int(sizes.sum())
+    return [o[:kept] for o in outs], sizes
 
 
 def assign_patches(ctx: Context, x, y, z, centers_xyz) -> np.ndarray:

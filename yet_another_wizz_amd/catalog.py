@@ -46,6 +46,7 @@ def _stable_argsort_small(keys, num_values: int):
 
 
 DEVICE_ASSIGN_MIN = 200_000  # below this the host is as fast as a round trip to the device
+HOST_GROUP_MIN = 200_000     # below this numpy's argsort + gathers are as fast as the library's threaded counting sort
 
 
 def nearest_center(xyz, centers_xyz, chunk: int = 1 << 18):
@@ -329,17 +330,26 @@ class Catalog(Mapping):
         if np.any(sizes == 0):  # same restriction as the reference (catalog.py:944-947)
             empty = np.flatnonzero(sizes == 0).tolist()
             raise ValueError(f"empty patches are not supported (patch ids {empty})")
-        order = _stable_argsort_small(patch_ids, num)
-        if np.all(patch_ids[1:] >= patch_ids[:-1]):
-            order = None  # already grouped by patch (a restored cache): the stable order is the identity, no gather
-        take = (lambda c: c) if order is None else (lambda c: _threads.take(c, order))
-        self._ra, self._dec = take(ra), take(dec)
-        self._w = None if weights is None else take(np.asarray_chkfinite(weights, dtype=np.float64))
-        self._z = None if redshifts is None else take(np.asarray_chkfinite(redshifts, dtype=np.float64))
-        self._patch_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        weights = None if weights is None else np.asarray_chkfinite(weights, dtype=np.float64)
+        redshifts = None if redshifts is None else np.asarray_chkfinite(redshifts, dtype=np.float64)
         # unit vectors: computed once per catalogue (assignment, patch metadata and the device layouts all use
         # these values -- the exact host numbers the pair predicate runs on)
-        self._xyz = radec_to_xyz(self._ra, self._dec) if xyz is None else tuple(take(np.asarray(c)) for c in xyz)
+        xyz = radec_to_xyz(ra, dec) if xyz is None else tuple(np.asarray(c, dtype=np.float64) for c in xyz)
+        columns = [ra, dec, *xyz] + [c for c in (weights, redshifts) if c is not None]
+        if np.all(patch_ids[1:] >= patch_ids[:-1]):
+            pass  # already grouped by patch (a restored cache): the stable order is the identity, no gather
+        elif len(ra) >= HOST_GROUP_MIN:  # one threaded counting sort over all columns (yawhip_host_group_columns)
+            from . import _lib
+
+            columns, _ = _lib.group_columns(patch_ids, num, columns)
+        else:
+            order = _stable_argsort_small(patch_ids, num)
+            columns = [c[order] for c in columns]
+        self._ra, self._dec, self._xyz = columns[0], columns[1], tuple(columns[2:5])
+        rest = iter(columns[5:])
+        self._w = None if weights is None else next(rest)
+        self._z = None if redshifts is None else next(rest)
+        self._patch_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self._layouts: dict = {}
         self._active_layout = None
         self.cache_directory = None if cache_directory is None else Path(cache_directory)
@@ -549,14 +559,23 @@ class Catalog(Mapping):
         else:
             num_bins = len(bins)
             bin_idx = bins.assign(self._z)
-            keep = np.flatnonzero(bin_idx >= 0)
             patch_of = np.repeat(np.arange(num_patches), np.diff(self._patch_off))
-            seg_key = patch_of[keep] * num_bins + bin_idx[keep]
-            order = keep[_stable_argsort_small(seg_key, num_patches * num_bins)]
             offsets = np.zeros(num_patches * num_bins + 1, dtype=np.int64)
-            np.cumsum(np.bincount(seg_key, minlength=num_patches * num_bins), out=offsets[1:])
-            layout = PatchLayout(_threads.take(x, order), _threads.take(y, order), _threads.take(z, order),
-                                 None if self._w is None else _threads.take(self._w, order), offsets, num_patches, num_bins)
+            columns = [x, y, z] + ([] if self._w is None else [self._w])
+            if len(x) >= HOST_GROUP_MIN:  # (patch, bin) grouping in one threaded pass; objects outside the binning dropped
+                from . import _lib
+
+                seg_key = np.where(bin_idx >= 0, patch_of * num_bins + bin_idx, -1)
+                columns, sizes = _lib.group_columns(seg_key, num_patches * num_bins, columns)
+                np.cumsum(sizes, out=offsets[1:])
+            else:
+                keep = np.flatnonzero(bin_idx >= 0)
+                seg_key = patch_of[keep] * num_bins + bin_idx[keep]
+                order = keep[_stable_argsort_small(seg_key, num_patches * num_bins)]
+                np.cumsum(np.bincount(seg_key, minlength=num_patches * num_bins), out=offsets[1:])
+                columns = [c[order] for c in columns]
+            layout = PatchLayout(columns[0], columns[1], columns[2], None if self._w is None else columns[3], offsets,
+                                 num_patches, num_bins)
         self._layouts[key] = layout
         self._active_layout = layout  # what the next count_pairs() uses, like the cached trees.pkl
         return layout

@@ -40,6 +40,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
+#include <utility>
 #include <vector>
 
 #include "yawhip.h"
@@ -934,7 +936,12 @@ auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
 // XCD's L2 instead of being fetched by all eight.
 //   UNI: all redshift bins share one threshold row (angular scales): edges live in registers.
 // ------------------------------------------------------------------------------------------------
-constexpr int BCAP = 160;  // window objects per LDS stage: 160 * 28 B + tables < 5 KB -> 32 single-wave workgroups per CU
+#ifndef YAW_BCAP
+#define YAW_BCAP 192
+#endif
+constexpr int BCAP = YAW_BCAP;  // window objects per LDS stage. 192: the window of a 128-object lane tile at equal densities (128 +- 11
+                                // entries + one band) fits in one stage; 6.2 KB -> 26 single-wave workgroups per CU. Measured
+                                // 160 / 176 / 192 / 208 / 224: count kernel 0.545 / 0.529 / 0.523 / 0.535 / 0.531 ms at the headline
 constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
 constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries
 
@@ -963,6 +970,7 @@ struct BandLds {  // byte offsets inside the static LDS image of a band workgrou
     static constexpr int FIXED = Z + COL;
 };
 static_assert(BandLds<160>::Y == 2064 && BandLds<160>::Z == 4128 && BandLds<160>::FIXED == 5424, "band LDS image");
+static_assert(BandLds<192>::FIXED == 6208, "band LDS image");
 // Stage capacities the band kernel is compiled for. A stage should hold the whole window of a lane tile (the tile's own
 // extent in streamed entries plus one band): a window cut into stages makes every stage wait for the longest clipped band
 // while the lanes whose bands lie in the other stage idle (50M x 50M, bands of 216 entries: 400 trips per 256 lane objects
@@ -1354,7 +1362,7 @@ struct yawhip_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
-    int band_cap = 0;        // entries per LDS stage of the band kernel: 0 = auto, 160, 288
+    int band_cap = 0;        // entries per LDS stage of the band kernel: 0 = auto, BCAP (192), BCAP_MID (288)
     int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
@@ -1873,7 +1881,7 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
     }
     if (!strcmp(key, "band_cap")) {
         if (value != 0 && value != BCAP && value != BCAP_MID)
-            return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 160 or 288");
+            return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 192 or 288");
         ctx->band_cap = (int)value;
         return YAWHIP_OK;
     }
@@ -2529,7 +2537,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         int64_t grid = strip_items && n_pot > 65536 ? n_pot / std::max(ctx->band_grid_div, 1) : n_pot;
         grid = std::min<int64_t>((grid + 7) & ~7ll, 1ll << 22);
         // 32-bit LDS counters: one stage adds at most 64 R x CAP to a cell, so flush at the latest every
-        // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 160-entry stages, 2^15 for four and 288)
+        // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 192-entry stages, 2^15 for four and 288)
         int flush_log2 = ctx->flush_log2;
         while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) > (1ull << 32)) --flush_log2;
         const unsigned flush_mask = (1u << flush_log2) - 1u;
@@ -2770,6 +2778,61 @@ uint64_t plan_key(const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_
 
 }  // namespace
 
+namespace {
+// Host-side grouping of catalogue columns (no device involved): a stable counting sort by key, run by a few threads.
+// Chunk c of the input counts its keys; group g then holds the entries of chunk 0, chunk 1, ... in input order, so every
+// chunk knows where its entries of every group go and scatters all columns in one pass over its slice.
+template <typename K>
+static int group_columns(int64_t n, const K *keys, int64_t num_groups, int32_t n_cols, const double *const *in, double *const *out,
+                         int64_t *sizes, int n_threads) {
+    const int64_t min_chunk = 1 << 16;
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads, (n + min_chunk - 1) / min_chunk));
+    std::vector<std::vector<int64_t>> hist((size_t)T, std::vector<int64_t>((size_t)num_groups, 0));
+    std::atomic<int> bad{0};
+    auto bounds = [&](int c) { return std::make_pair(n * c / T, n * (c + 1) / T); };
+    auto run = [&](auto &&fn) {
+        if (T == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int c = 0; c < T; ++c) th.emplace_back(fn, c);
+        for (auto &t : th) t.join();
+    };
+    run([&](int c) {
+        auto [lo, hi] = bounds(c);
+        int64_t *h = hist[(size_t)c].data();
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t k = (int64_t)keys[i];
+            if (k >= num_groups) { bad.store(1); return; }
+            if (k >= 0) ++h[k];
+        }
+    });
+    if (bad.load()) return fail(YAWHIP_ERR_INVALID, "yawhip_host_group_columns: key >= num_groups");
+    int64_t at = 0;
+    for (int64_t g = 0; g < num_groups; ++g) {
+        int64_t size = 0;
+        for (int c = 0; c < T; ++c) {
+            const int64_t cnt = hist[(size_t)c][(size_t)g];
+            hist[(size_t)c][(size_t)g] = at + size;  // first slot of chunk c in group g
+            size += cnt;
+        }
+        sizes[g] = size;
+        at += size;
+    }
+    if (n_cols > 0)
+        run([&](int c) {
+            auto [lo, hi] = bounds(c);
+            int64_t *h = hist[(size_t)c].data();
+            for (int64_t i = lo; i < hi; ++i) {
+                const int64_t k = (int64_t)keys[i];
+                if (k < 0) continue;
+                const int64_t dst = h[k]++;
+                for (int32_t col = 0; col < n_cols; ++col) out[col][dst] = in[col][i];
+            }
+        });
+    return YAWHIP_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
@@ -2921,6 +2984,24 @@ int yawhip_assign_patches(yawhip_ctx *ctx, int64_t n, const double *x, const dou
     if (e != hipSuccess)
         return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "yawhip_assign_patches failed: %s", hipGetErrorString(e));
     return YAWHIP_OK;
+}
+
+int yawhip_host_group_columns(int64_t n, const void *keys, int32_t key_bytes, int64_t num_groups, int32_t n_cols,
+                              const double *const *in, double *const *out, int64_t *sizes, int32_t n_threads) {
+    if (n < 0 || num_groups <= 0 || n_cols < 0 || !sizes || (n > 0 && !keys) || (key_bytes != 4 && key_bytes != 8))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_host_group_columns: bad sizes or NULL arrays");
+    for (int32_t c = 0; c < n_cols; ++c)
+        if (n > 0 && (!in || !out || !in[c] || !out[c] || in[c] == out[c]))
+            return fail(YAWHIP_ERR_INVALID, "yawhip_host_group_columns: column %d is NULL or aliases its output", c);
+    if (n_threads <= 0) n_threads = (int32_t)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    try {
+        return key_bytes == 4 ? group_columns(n, (const int32_t *)keys, num_groups, n_cols, in, out, sizes, n_threads)
+                              : group_columns(n, (const int64_t *)keys, num_groups, n_cols, in, out, sizes, n_threads);
+    } catch (const std::bad_alloc &) {
+        return fail(YAWHIP_ERR_OOM, "yawhip_host_group_columns: out of host memory");
+    } catch (const std::system_error &err) {
+        return fail(YAWHIP_ERR_INVALID, "yawhip_host_group_columns: %s", err.what());
+    }
 }
 
 int yawhip_job_work(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs,
