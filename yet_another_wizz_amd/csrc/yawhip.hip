@@ -990,6 +990,19 @@ __device__ __forceinline__ __attribute__((address_space(3))) void *lds_ptr(unsig
 __device__ __forceinline__ double lds_f64(unsigned addr) { return *(const __attribute__((address_space(3))) double *)(size_t)addr; }
 __device__ __forceinline__ int lds_i32(unsigned addr) { return *(const __attribute__((address_space(3))) int *)(size_t)addr; }
 
+// Maximum of a non-negative int over the 64 lanes of the wave, as a scalar: four row shifts, two row broadcasts (DPP, in
+// the VALU) and one readlane -- the shuffle form goes through the LDS crossbar six times, each with its own wait.
+__device__ __forceinline__ int wave_max_nonneg(int v) {
+    // update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl): lanes without a source lane keep old = 0, the identity
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));  // row_shr:8 -> lane 15 of a row holds the row's maximum
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // NE: edges per bin known at compile time (2: one fine bin; 3, 4: edges in registers when every bin -- or the item -- has one
 // row of them); 0: any number, edge table in LDS.
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
@@ -1040,7 +1053,6 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
         const DevTab c1 = tabs[o], c2 = tabs[3 + o];  // wave-uniform: scalar loads
-        const double *skey = c2.axis == 0 ? sx : (c2.axis == 1 ? sy : sz);  // sort-axis column of the stage
         const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
         int64_t b0 = it.b0[0], nb_total = it.nb[0];  // the current window (an item of the strip builder carries up to three)
@@ -1150,26 +1162,31 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                 for (int e = lane; e < n; e += 64) sw[e] = 1.0;
             __syncthreads();
             // band of the lane inside this stage: [lo, hi) = entries with klo <= key <= khi
-            int lo = 0, hi = 0;
-            const int top = 1 << (31 - __builtin_clz(n));  // largest power of two <= n
+            // Both searches run on LDS byte addresses: q = address of entry (lo - 1). A probe beyond the stage is clamped
+            // onto the sentinel (4.0 > every key bound), which fails both comparisons by itself -- no index checks, and
+            // hipcc keeps the loop free of branches (the index form compiled to twice the instructions, with the
+            // second read under an exec branch).
+            const unsigned a_key = a_sx + (c2.axis == 0 ? 0u : (c2.axis == 1 ? (unsigned)(LDS_Y - LDS_X) : (unsigned)(LDS_Z - LDS_X)));
+            const unsigned a_sent = a_key + ((unsigned)n << 3);
+            unsigned ql = a_key - 8u, qh = ql;
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
-            for (int step = 0; step > 0; step >>= 1) {  // diagnostics: no search either
+            for (unsigned step8 = 0; step8 >= 8u; step8 >>= 1) {  // diagnostics: no search either
 #else
-            for (int step = top; step > 0; step >>= 1) {
+            for (unsigned step8 = 8u << (31 - __builtin_clz(n)); step8 >= 8u; step8 >>= 1) {  // largest power of two <= n
 #endif
-                const int pl = lo + step, ph = hi + step;
-                const double kl = skey[(pl < n ? pl : n) - 1], kh = skey[(ph < n ? ph : n) - 1];
-                lo = (pl <= n && kl < klo) ? pl : lo;    // entries [0, lo) have key <  klo
-                hi = (ph <= n && kh <= khi) ? ph : hi;   // entries [0, hi) have key <= khi
+                const unsigned pl = ql + step8, ph = qh + step8;
+                const double kl = lds_f64(pl < a_sent ? pl : a_sent), kh = lds_f64(ph < a_sent ? ph : a_sent);
+                ql = kl < klo ? pl : ql;    // entries [0, lo) have key <  klo
+                qh = kh <= khi ? ph : qh;   // entries [0, hi) have key <= khi
             }
+            int lo = (int)((ql + 8u - a_key) >> 3), hi = (int)((qh + 8u - a_key) >> 3);
             if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
             int len = hi - lo;
             nev += (unsigned int)(len * n_own);
-            for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1
             const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
 #else
-            const int steps = __builtin_amdgcn_readfirstlane(len);  // the longest band of the wave: uniform trip count
+            const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
 #endif
 
             // Walk the band, one entry per trip, evaluated against the lane's R objects. A lane whose band has ended moves
