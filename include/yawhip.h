@@ -91,6 +91,8 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
 
 /* Tunables (all optional):
  *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)
+ *   "hist_copies_log2"  band kernel: log2 of the copies of its LDS histogram (-1 = auto: 4 copies for few slots, up to 16
+ *                       for per-bin items or when neighbouring objects of a binned catalogue mostly share their bin; 0..6)
  *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 192, or 288 when a lane tile's window is
  *                       expected to need more; 192; 288)
  *   "kernel"            default yawhip_kernel of yawhip_count_pairs(kernel = AUTO)
