@@ -155,7 +155,7 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
  *   kernel     yawhip_kernel
  * Pair (a in c1 segment (p,k), b in c2 segment (q,k)) belongs to fine bin e (0 <= e < E-1) iff
  *       t[k][e] < s <= t[k][e+1],   s = ((ax-bx)^2 + (ay-by)^2) + (az-bz)^2   in float64 without FMA.
- * Outputs (either may be NULL):
+ * Outputs (either may be NULL; on success every element is written, the caller need not clear them):
  *   fine_counts  int64[n_jobs][B][E-1]  number of pairs            (bit exact)
  *   fine_sums    float64[n_jobs][B][E-1] sum of w_a * w_b, a missing weight column counts as 1.0.
  *                No floating point atomics touch global memory: per-item partial sums are combined in a fixed
@@ -193,6 +193,18 @@ int yawhip_assign_patches(yawhip_ctx *ctx, int64_t n, const double *x, const dou
  */
 int yawhip_host_group_columns(int64_t n, const void *keys, int32_t key_bytes, int64_t num_groups, int32_t n_cols,
                               const double *const *in, double *const *out, int64_t *sizes, int32_t n_threads);
+
+/*
+ * Host-only helper of the epilogue: the dense result tensor from the per-job values -- the loop
+ * counts[:, id1, id2] = result (x 0.5 on the diagonal of an autocorrelation) of PatchLinkage.count_pairs
+ * (correlation/measurements.py:358-364), for all scales and bins at once.
+ *   out         float64[n_rows][row_len], zero-filled, then out[r][cols[j]] = vals[r][j] * (col_factor ? col_factor[j] : 1)
+ *               (n_rows = scales x bins, row_len = P x P, cols[j] = id1 * P + id2 of job j)
+ *   vals        float64, element (r, j) at vals[r * val_row_stride + j * val_col_stride] (strides in elements: the per-job
+ *               values arrive job-major from yawhip_count_pairs)
+ */
+int yawhip_host_scatter_rows(int64_t n_rows, int64_t row_len, double *out, int64_t n_cols, const int64_t *cols,
+                             const double *vals, int64_t val_row_stride, int64_t val_col_stride, const double *col_factor);
 
 /*
  * Evaluated pair distances per job, without counting anything: runs the item builder of yawhip_count_pairs for the

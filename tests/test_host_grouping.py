@@ -64,3 +64,24 @@ def test_catalog_setup_is_the_same_through_the_library_and_through_numpy(monkeyp
         for name in ("x", "y", "z", "w", "sum_weights"):
             assert np.array_equal(getattr(l1, name), getattr(l2, name)), name
     assert la.num_records < n  # some redshifts lie outside the binning
+
+
+def test_scatter_rows_matches_numpy():
+    """yawhip_host_scatter_rows (dense [S, B, P, P] tensor from per-job values) against zeros + fancy assignment, for
+    contiguous values and for the transposed view the job-major device result arrives as."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(3)
+    S, B, P, J = 2, 5, 7, 19
+    cols = np.sort(rng.choice(P * P, J, replace=False)).astype(np.int64)
+    factor = rng.choice([0.5, 1.0], J)
+    for vals in (rng.random((S, B, J)), np.moveaxis(rng.random((J, B, 1)), 0, -1)[:, 0][np.newaxis]):
+        s_ = vals.shape[0]
+        for f in (None, factor):
+            exp = np.zeros((s_ * B, P * P))
+            exp[:, cols] = vals.reshape(s_ * B, J) * (1.0 if f is None else f)
+            got = _lib.scatter_rows((s_, B, P, P), cols, vals, f)
+            assert got.shape == (s_, B, P, P) and np.array_equal(got.reshape(s_ * B, P * P), exp)
+    assert not _lib.scatter_rows((1, 2, 3, 3), np.zeros(0, dtype=np.int64), np.zeros((1, 2, 0))).any()
+    with pytest.raises(_lib.YawhipError, match="out of range"):
+        _lib.scatter_rows((1, 1, 2, 2), np.array([4], dtype=np.int64), np.ones((1, 1, 1)))

@@ -38,6 +38,7 @@ ABI_SYMBOLS = (
     "yawhip_job_work",
     "yawhip_assign_patches",
     "yawhip_host_group_columns",
+    "yawhip_host_scatter_rows",
 )
 
 
@@ -128,6 +129,8 @@ def load_library() -> ctypes.CDLL:
         ctypes.c_int64, _vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(_dp), ctypes.POINTER(_dp), _i64p,
         ctypes.c_int32,
     ]
+    lib.yawhip_host_scatter_rows.argtypes = [ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int64, _vp, _vp, ctypes.c_int64,
+                                             ctypes.c_int64, _vp]
     for name in ABI_SYMBOLS:
         fn = getattr(lib, name)
         if name != "yawhip_last_error":
@@ -255,8 +258,8 @@ def count_pairs(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresh
     if want_sums is None:
         want_sums = weighted
     shape = (len(jobs), n_bins, max(n_edges - 1, 0))
-    counts = np.zeros(shape, dtype=np.int64) if want_counts else None
-    sums = np.zeros(shape, dtype=np.float64) if want_sums else None
+    counts = np.empty(shape, dtype=np.int64) if want_counts else None   # the library writes every element it is asked for
+    sums = np.empty(shape, dtype=np.float64) if want_sums else None
     st = _Stats()
     kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
     _check(
@@ -306,6 +309,28 @@ def group_columns(keys, num_groups: int, columns, n_threads: int = 0):
     )
     kept = int(sizes.sum())
     return [o[:kept] for o in outs], sizes
+
+
+def scatter_rows(shape, cols, vals, col_factor=None) -> np.ndarray:
+    """``yawhip_host_scatter_rows``: zeros(shape) viewed as [rows, row_len] with ``out[r, cols[j]] = vals[..., j]``
+    (times ``col_factor[j]``). ``cols`` int64[n]; ``vals`` float64[..., n], its leading axes are the rows (any strides
+    that make the rows equidistant, e.g. a transposed view of the job-major device result)."""
+    out = np.empty(shape, dtype=np.float64)
+    n_cols = len(cols)
+    if n_cols == 0 or vals.size == 0:
+        out[...] = 0.0
+        return out
+    vals2 = vals.reshape(-1, n_cols) if vals.ndim != 2 else vals  # a view whenever the strides allow it
+    if vals2.dtype != np.float64 or vals2.strides[0] % 8 or vals2.strides[1] % 8:
+        vals2 = np.ascontiguousarray(vals2, dtype=np.float64)
+    n_rows = vals2.shape[0]
+    if out.size % n_rows or cols.dtype != np.int64 or not cols.flags.c_contiguous:
+        raise ValueError("scatter_rows: shape / cols do not fit the values")
+    rc = load_library().yawhip_host_scatter_rows(
+        n_rows, out.size // n_rows, out.ctypes.data, n_cols, cols.ctypes.data, vals2.ctypes.data,
+        vals2.strides[0] // 8, vals2.strides[1] // 8, None if col_factor is None else col_factor.ctypes.data)
+    _check(rc, "yawhip_host_scatter_rows")
+    return out
 
 
 def assign_patches(ctx: Context, x, y, z, centers_xyz) -> np.ndarray:

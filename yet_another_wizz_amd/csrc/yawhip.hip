@@ -3064,6 +3064,24 @@ int yawhip_host_group_columns(int64_t n, const void *keys, int32_t key_bytes, in
     }
 }
 
+int yawhip_host_scatter_rows(int64_t n_rows, int64_t row_len, double *out, int64_t n_cols, const int64_t *cols,
+                             const double *vals, int64_t val_row_stride, int64_t val_col_stride, const double *col_factor) {
+    if (n_rows < 0 || row_len < 0 || n_cols < 0 || (n_rows * row_len > 0 && !out) || (n_cols > 0 && (!cols || (n_rows > 0 && !vals))))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_host_scatter_rows: bad sizes or NULL arrays");
+    for (int64_t j = 0; j < n_cols; ++j)
+        if (cols[j] < 0 || cols[j] >= row_len) return fail(YAWHIP_ERR_INVALID, "yawhip_host_scatter_rows: column %lld out of range", (long long)cols[j]);
+    memset(out, 0, sizeof(double) * (size_t)(n_rows * row_len));
+    for (int64_t r = 0; r < n_rows; ++r) {
+        double *dst = out + r * row_len;
+        const double *src = vals + r * val_row_stride;
+        if (col_factor)
+            for (int64_t j = 0; j < n_cols; ++j) dst[cols[j]] = src[j * val_col_stride] * col_factor[j];
+        else
+            for (int64_t j = 0; j < n_cols; ++j) dst[cols[j]] = src[j * val_col_stride];
+    }
+    return YAWHIP_OK;
+}
+
 int yawhip_job_work(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs,
                     int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel, int64_t *work) {
     if (!ctx || !work) return fail(YAWHIP_ERR_INVALID, "yawhip_job_work: NULL argument");

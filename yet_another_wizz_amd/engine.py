@@ -56,13 +56,24 @@ def release() -> None:
     _contexts.clear()
 
 
+_strip_micro_cache: dict = {}
+
+
 def strip_micro_for(thresholds) -> int:
     """Spacing of the strip grid (1e-6 chord units) that suits the widest separation of a threshold
     table: just above the largest chord, so that a run has partners in three strips only and those are
     as narrow as possible. Measured on the 10M x 10M headline (chord 2909): 2950 -> 2.09 ms per step,
     3600 -> 2.16, 4400 -> 2.21, 5200 -> 2.28; below the chord five strips take part (2000: 30 % slower)."""
+    key = (id(thresholds), thresholds.shape)
+    hit = _strip_micro_cache.get(key)
+    if hit is not None and hit[0] is thresholds:  # threshold tables are built once per configuration and never modified
+        return hit[1]
     r = float(np.sqrt(np.max(thresholds)))
-    return int(min(max(np.ceil(1.02e6 * r / 50.0) * 50.0, 1000), 100000))
+    micro = int(min(max(np.ceil(1.02e6 * r / 50.0) * 50.0, 1000), 100000))
+    if len(_strip_micro_cache) > 16:
+        _strip_micro_cache.clear()
+    _strip_micro_cache[key] = (thresholds, micro)
+    return micro
 
 
 def device_catalog(layout, ctx=None, sort_axis: int = 2, strip_micro: int | None = None,

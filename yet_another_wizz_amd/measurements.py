@@ -16,7 +16,7 @@ from itertools import compress
 
 import numpy as np
 
-from . import engine, parallel
+from . import _lib, engine, parallel
 from .angular_bins import plan_for_limits
 from .catalog import Catalog, InconsistentPatchesError
 from .coordinates import AngularDistances
@@ -275,7 +275,7 @@ class PatchLinkage:
         # per GPU under torch.distributed: the jobs are sharded over the ranks here and one sum all-reduce combines
         # the result (every slot is non-zero on exactly one rank: the sum is exact and order independent).
         rank, size = parallel.world()
-        mine = np.arange(len(jobs))
+        mine = None  # every job
         if size > 1:
             # balance what the device will really evaluate (lane tile x window sizes, from the item builder); the
             # partition is a plan: rank 0 derives it once per (catalogue pair, group size) and broadcasts it
@@ -289,8 +289,8 @@ class PatchLinkage:
             mine = self._partitions[key][rank]
         failure = None
         try:
-            fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis,
-                                            max_workers=max_workers)
+            fine, stats = engine.count_fine(layout1, layout2, jobs if mine is None else jobs[mine], thresholds,
+                                            sort_axis=self.sort_axis, max_workers=max_workers)
             self.last_stats = stats
         except Exception as err:  # noqa: BLE001 -- with several ranks the others must not wait for this one forever
             if size == 1:
@@ -319,18 +319,14 @@ class PatchLinkage:
         # counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364), scatter into [B, P, P]
         num_scales = self.config.scales.num_scales
         per_scale = self._combine(fine_bej)  # [S, B, n_jobs]
-        skey = (auto, num_patches, num_scales, num_bins)
-        if skey not in self._scatter:  # position of every (scale, bin, job) in the dense tensor and the diagonal factor
-            flat = id1.astype(np.int64) * num_patches + id2
-            full = (np.arange(num_scales * num_bins, dtype=np.int64)[:, np.newaxis] * (num_patches * num_patches)
-                    + flat[np.newaxis, :]).ravel()
+        skey = (auto, num_patches)
+        if skey not in self._scatter:  # position of every job in a [P, P] slice and the diagonal factor
+            flat = np.ascontiguousarray(id1.astype(np.int64) * num_patches + id2)
             halve = np.where(id1 == id2, 0.5, 1.0) if auto else None
-            self._scatter[skey] = (full, halve)
-        full, halve = self._scatter[skey]
-        if halve is not None:
-            per_scale = per_scale * halve
-        counts = np.zeros((num_scales, num_bins, num_patches, num_patches), dtype=np.float64)
-        counts.put(full, per_scale)  # C order on both sides: [S, B, jobs] -> [S, B, i * P + j]
+            self._scatter[skey] = (flat, halve)
+        flat, halve = self._scatter[skey]
+        # [S, B, jobs] -> [S, B, i * P + j], zero elsewhere (one pass in the library: yawhip_host_scatter_rows)
+        counts = _lib.scatter_rows((num_scales, num_bins, num_patches, num_patches), flat, per_scale, halve)
         scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(num_scales)]
 
         sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
