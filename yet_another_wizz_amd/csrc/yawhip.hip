@@ -18,9 +18,12 @@
 //   * k_count (EXACT / FILTER, non-unit input): 256-thread workgroups, 256*R lane objects in registers, the
 //     c1 segment streamed through LDS; 8 FP64 ops + compare per pair, or a conservative FP32 dot-product test
 //     first and exact FP64 for its survivors. Per-lane private LDS histograms, fixed-order reduction;
-//   * k_count_merged (SWEEP, the default): single-wave workgroups, float32 only on chip (packed v_pk_fma_f32),
+//   * k_count_merged (SWEEP): single-wave workgroups, float32 only on chip (packed v_pk_fma_f32),
 //     survivors queued per wave and evaluated 64 at a time in exact FP64; one item of the cross-correlation
-//     path covers all redshift bins.
+//     path covers all redshift bins. AUTO uses it on layouts without strips and for sparse streamed runs;
+//   * k_count_band (BAND, what AUTO runs on strip layouts -- the headline): single-wave workgroups, the window of a
+//     lane tile staged in LDS by LDS-DMA, every lane walks only the band |du| <= r of its two neighbouring objects
+//     and decides every entry with the exact FP64 predicate (no pre-filter, no queue).
 // Unweighted counts: uint32 LDS histograms -> 64-bit integer atomics. Weighted sums: per-item slabs (LDS float64
 // atomics private to one wave) reduced in a fixed two-level order -> bit-reproducible run to run. No floating
 // point atomics in global memory.
