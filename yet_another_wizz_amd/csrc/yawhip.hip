@@ -983,9 +983,9 @@ constexpr int BCAP_MID = 288;
 inline int band_lds_fixed(int cap) { return cap == BCAP_MID ? BandLds<BCAP_MID>::FIXED : BandLds<BCAP>::FIXED; }
 __host__ __device__ inline bool band_small_hist(bool weighted, int nslots, int hp) { return (size_t)nslots * hp * (weighted ? 8 : 4) <= 512; }
 // dynamic LDS bytes of a band workgroup (host and device agree through this one function)
-__host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp, int cap) {
+__host__ __device__ inline size_t band_lds_dynamic(bool weighted, bool need_thr, int nkb, int n_edges, int hp, int cap, int thr_rows) {
     const int nslots = nkb * (n_edges - 1);
-    return (weighted ? (size_t)(cap + 2) * 8 : 0) + (need_thr ? (size_t)nkb * n_edges * sizeof(double) : 0) +
+    return (weighted ? (size_t)(cap + 2) * 8 : 0) + (need_thr ? (size_t)thr_rows * n_edges * sizeof(double) : 0) +
            (band_small_hist(weighted, nslots, hp) ? 0 : (size_t)nslots * hp * (weighted ? 8 : 4)) + 16;
 }
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
     int *sk = reinterpret_cast<int *>(lds_fix + LDS_K);
     unsigned char *p = lds_dyn;
     double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += BCOL;
-    double *thr = reinterpret_cast<double *>(p); if (NEED_THR) p += (size_t)nkb * n_edges * sizeof(double);   // [nkb][n_edges]
+    const int thr_rows = (MERGED && !UNI) ? nkb : 1;  // one edge row when every bin (or the item's only bin) shares it
+    double *thr = reinterpret_cast<double *>(p); if (NEED_THR) p += (size_t)thr_rows * n_edges * sizeof(double);  // [thr_rows][n_edges]
     const bool small_hist = band_small_hist(WEIGHTED, nslots, hp);
     HistT *hist = reinterpret_cast<HistT *>(small_hist ? lds_fix + LDS_H : p);                                // [nslots][hp]
     unsigned int *dummy = reinterpret_cast<unsigned int *>(lds_fix + LDS_H + LDS_H_BYTES);                    // [64] one cell per lane for misses
@@ -1107,7 +1108,11 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
             for (int q = 0; q < NE; ++q) ed[q] = t[(int64_t)kfix * n_edges + q];
         }
         if (NEED_THR)
-            for (int e = lane; e < nkb * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
+            for (int e = lane; e < thr_rows * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
+        // outer edges of the one row in registers; largest power of two <= the number of inner edges (fine-bin search)
+        const double e_lo = NEED_THR && thr_rows == 1 ? t[(int64_t)kfix * n_edges] : 0.0;
+        const double e_hi = NEED_THR && thr_rows == 1 ? t[(int64_t)kfix * n_edges + n_edges - 1] : 0.0;
+        const int edge_top = n_edges > 2 ? 1 << (31 - __builtin_clz(n_edges - 2)) : 0;
         for (int e = lane; e < nslots * hp; e += 64) hist[e] = HistT(0);
         // the lane's band: from the first object's lower to the last object's upper bound (the tile is sorted along u)
         double klo, khi;
@@ -1226,8 +1231,10 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                         in = sd > ed[0] && sd <= ed[NE - 1];
                         if constexpr (NE >= 3) slot += (sd > ed[1]) ? 1 : 0;  // inner edges: t[c-1] < s <= t[c]
                         if constexpr (NE >= 4) slot += (sd > ed[2]) ? 1 : 0;
+                    } else if (thr_rows == 1) {
+                        in = sd > e_lo && sd <= e_hi;
                     } else {
-                        const double *tk = thr + (MERGED ? kb[r] * n_edges : 0);  // edge row of the entry's bin
+                        const double *tk = thr + kb[r] * n_edges;  // edge row of the entry's bin
                         in = sd > tk[0] && sd <= tk[n_edges - 1];
                     }
                     if (NF1 && !MERGED && !WEIGHTED) {
@@ -1240,10 +1247,15 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else if (in) {
                         if constexpr (!REG_EDGES) {
-                            const double *tk = thr + (MERGED ? kb[r] * n_edges : 0);
+                            // fine bin = number of inner edges below s: a branch-free binary search over the sorted row
+                            // (a probe past the inner edges reads the last edge, which s does not exceed)
+                            const double *tk = thr + (thr_rows == 1 ? 0 : kb[r] * n_edges);
                             int c = 0;
-                            for (int q = 0; q < n_edges; ++q) c += (sd > tk[q]) ? 1 : 0;
-                            slot += c - 1;  // t[c-1] < s <= t[c], c >= 1 because s > t[0]
+                            for (int step = edge_top; step > 0; step >>= 1) {
+                                const int probe = c + step;
+                                c = sd > tk[probe < n_edges - 1 ? probe : n_edges - 1] ? probe : c;
+                            }
+                            slot += c;  // t[c] < s <= t[c + 1]
                         }
                         // The histogram belongs to this wave alone: integer adds are exact; float64 adds of ONE instruction
                         // that hit the same cell are serialised by the LDS in a fixed lane order -> reproducible sums.
@@ -2353,7 +2365,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     if (ctx->hist_copies_log2 >= 0) hp_shift = ctx->hist_copies_log2;
     const int band_ne = (!merged || uniform_t) && n_edges <= 4 ? n_edges : (nf == 1 ? 2 : 0);  // compile-time edge count of k_count_band
     const bool band_thr = !(band_ne >= 2 && (!merged || uniform_t));
-    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, cap);
+    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, cap, merged && !uniform_t ? lean_bins : 1);
     const size_t LDS_FIXED = (size_t)band_lds_fixed(cap);
     if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
