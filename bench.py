@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--scales", type=int, default=1, choices=[1, 3],
                     help="1: one scale 1-10 arcmin; 3: the log-spaced scales of BASELINE config #5 (0.5-15.8 arcmin)")
     ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5) on both catalogues")
+    ap.add_argument("--kpc", action="store_true", help="physical scales 100-1000 kpc (thresholds differ from bin to bin) instead of 1-10 arcmin")
     ap.add_argument("--rweight", type=float, default=None, help="separation weight r**rweight (Configuration rweight; resolution 50)")
     return ap.parse_args()
 
@@ -103,7 +104,10 @@ def make_catalogs(args, inputs=None):
     else:
         rmin, rmax = 1.0, 10.0
     extra = {} if getattr(args, "rweight", None) is None else dict(rweight=args.rweight, resolution=50)
-    config = yaw.Configuration.create(rmin=rmin, rmax=rmax, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=args.zbins, **extra)
+    unit = "arcmin"
+    if getattr(args, "kpc", False):
+        rmin, rmax, unit = 100.0, 1000.0, "kpc"
+    config = yaw.Configuration.create(rmin=rmin, rmax=rmax, unit=unit, zmin=0.1, zmax=1.0, num_bins=args.zbins, **extra)
     return config, ref, unk
 
 

@@ -466,6 +466,7 @@ def test_randomised_configurations(ctx, seed):
         ctx.set_option("tile_r", int(rng.choice([0, 1, 2, 4])))
         ctx.set_option("band_cap", int(rng.choice([0, 192, 288])))  # LDS stage capacity of the band kernel
         ctx.set_option("hist_copies_log2", int(rng.choice([-1, 0, 2, 4])))  # copies of its LDS histogram
+        ctx.set_option("band_batch_log2", int(rng.choice([-1, 0, 1, 3])))  # consecutive items per workgroup visit
         up = lambda c: _lib.DeviceCatalog(ctx, c["x"], c["y"], c["z"], c["w"], P, c["nb"], c["off"], sort_axis=axis)
         d1, d2 = up(c1), up(c2)
         for a, b, da, db in ((c1, c2, d1, d2), (c1, c1, d1, d1)):
@@ -484,6 +485,7 @@ def test_randomised_configurations(ctx, seed):
         ctx.set_option("tile_r", 0)
         ctx.set_option("band_cap", 0)
         ctx.set_option("hist_copies_log2", -1)
+        ctx.set_option("band_batch_log2", -1)
 
 
 @pytest.mark.parametrize("weights", ["uu", "ww"])

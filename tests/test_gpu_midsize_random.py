@@ -80,6 +80,7 @@ def test_culling_paths_equal_brute_force(ctx, seed):
                 ctx.set_option("tile_r", int(rng.choice([0, 1, 2, 4])))
                 ctx.set_option("band_cap", int(rng.choice([0, 192, 288])))
                 ctx.set_option("hist_copies_log2", int(rng.choice([-1, 0, 3])))
+                ctx.set_option("band_batch_log2", int(rng.choice([-1, 0, 2, 4])))
                 counts, sums, stats = _lib.count_pairs(ctx, da, db, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
                 assert np.array_equal(counts, exp_c), (seed, kernel)
                 if weighted:
@@ -88,5 +89,6 @@ def test_culling_paths_equal_brute_force(ctx, seed):
                     assert np.array_equal(sums, exp_c.astype(np.float64))
                 assert stats.candidate_pairs == st.candidate_pairs
     finally:
-        for key, val in (("strip_width_micro", _lib.DEFAULT_STRIP_MICRO), ("tile_r", 0), ("band_cap", 0), ("hist_copies_log2", -1)):
+        for key, val in (("strip_width_micro", _lib.DEFAULT_STRIP_MICRO), ("tile_r", 0), ("band_cap", 0), ("hist_copies_log2", -1),
+                         ("band_batch_log2", -1)):
             ctx.set_option(key, val)

@@ -1012,7 +1012,7 @@ template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
 __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                    int n_edges, const double *__restrict__ t,
                                                    const double *__restrict__ rwin_k, unsigned flush_mask, int hp_shift,
-                                                   unsigned long long *__restrict__ out_counts,
+                                                   int batch_log2, unsigned long long *__restrict__ out_counts,
                                                    double *__restrict__ partials,
                                                    unsigned long long *__restrict__ counters) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
     int *sk = reinterpret_cast<int *>(lds_fix + LDS_K);
     unsigned char *p = lds_dyn;
     double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += BCOL;
-    const int thr_rows = (MERGED && !UNI) ? nkb : 1;  // one edge row when every bin (or the item's only bin) shares it
+    constexpr bool ROW1 = !(MERGED && !UNI);          // one edge row: every bin (or the item's only bin) shares it
+    const int thr_rows = ROW1 ? 1 : nkb;
     double *thr = reinterpret_cast<double *>(p); if (NEED_THR) p += (size_t)thr_rows * n_edges * sizeof(double);  // [thr_rows][n_edges]
     const bool small_hist = band_small_hist(WEIGHTED, nslots, hp);
     HistT *hist = reinterpret_cast<HistT *>(small_hist ? lds_fix + LDS_H : p);                                // [nslots][hp]
@@ -1049,13 +1050,43 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 
     const unsigned long long n_kept = counters[0];
     const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    // A workgroup takes 2^batch_log2 CONSECUTIVE items at a time and carries its (unweighted) histogram from one to the
+    // next while they add to the same output slot -- consecutive items are lane tiles of one job -- so a histogram of
+    // hundreds of cells (separation weights: 51 fine bins x 30 z-bins) goes to global memory once per batch, not once per
+    // item: the global atomics of the flush were four fifths of that case's time. Few cells: batches of one (finer balance).
+    const unsigned long long n_batches = (chunk + (1ull << batch_log2) - 1) >> batch_log2;
+    for (int e = lane; e < nslots * hp; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
+    unsigned int cnt1 = 0;             // NF1 && !MERGED: the only counter lives in a register
+    unsigned stage_no = 0;
+    int pend_slot = -1;                // output slot the histogram holds counts for (unweighted)
+    int thr_k = -1;                    // bin whose edge row the LDS table holds
+    auto flush_counts = [&](int slot_out) {  // LDS histogram / register counter -> global result (unweighted)
+        if (NF1 && !MERGED) {
+            if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)slot_out * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
+            cnt1 = 0;
+            return;
+        }
+        __syncthreads();
+        for (int idx = lane; idx < nslots; idx += 64) {
+            unsigned int c = 0;
+            for (int h = 0; h < hp; ++h) {
+                c += (unsigned int)hist[idx * hp + h];
+                hist[idx * hp + h] = HistT(0);
+            }
+            if (c) atomicAdd(&out_counts[(int64_t)slot_out * nslots + idx], (unsigned long long)c);
+        }
+    };
     for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
-        const unsigned long long j = v >> 3;
-        if (j >= chunk) break;
+        if ((v >> 3) >= n_batches) break;
+      for (unsigned long long j = (v >> 3) << batch_log2; j < (((v >> 3) + 1) << batch_log2) && j < chunk; ++j) {
         const unsigned long long ticket = (v & 7) * chunk + j;
-        if (ticket >= n_kept) continue;  // short last eighth
+        if (ticket >= n_kept) break;  // short last eighth
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
+        if (!WEIGHTED) {
+            if (pend_slot >= 0 && pend_slot != islot) flush_counts(pend_slot);
+            pend_slot = islot;
+        }
         const DevTab c1 = tabs[o], c2 = tabs[3 + o];  // wave-uniform: scalar loads
         const int kfix = MERGED ? 0 : islot % n_bins;
         const double rwin = rwin_k[kfix];
@@ -1107,13 +1138,14 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 #pragma unroll
             for (int q = 0; q < NE; ++q) ed[q] = t[(int64_t)kfix * n_edges + q];
         }
-        if (NEED_THR)
+        if (NEED_THR && thr_k != kfix) {  // (the barriers of the first stage come before anyone reads it)
             for (int e = lane; e < thr_rows * n_edges; e += 64) thr[e] = t[(int64_t)kfix * n_edges + e];
+            thr_k = kfix;
+        }
         // outer edges of the one row in registers; largest power of two <= the number of inner edges (fine-bin search)
-        const double e_lo = NEED_THR && thr_rows == 1 ? t[(int64_t)kfix * n_edges] : 0.0;
-        const double e_hi = NEED_THR && thr_rows == 1 ? t[(int64_t)kfix * n_edges + n_edges - 1] : 0.0;
+        const double e_lo = NEED_THR && ROW1 ? t[(int64_t)kfix * n_edges] : 0.0;
+        const double e_hi = NEED_THR && ROW1 ? t[(int64_t)kfix * n_edges + n_edges - 1] : 0.0;
         const int edge_top = n_edges > 2 ? 1 << (31 - __builtin_clz(n_edges - 2)) : 0;
-        for (int e = lane; e < nslots * hp; e += 64) hist[e] = HistT(0);
         // the lane's band: from the first object's lower to the last object's upper bound (the tile is sorted along u)
         double klo, khi;
         {
@@ -1128,24 +1160,16 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 #pragma unroll
         for (int r = 0; r < R; ++r)  // slots without an object sit beyond every edge of every entry
             if (r >= n_own) { ax[r] = PAD_COORD; ay[r] = PAD_COORD; az[r] = PAD_COORD; aw[r] = 0.0; }
-        unsigned int cnt1 = 0;             // NF1 && !MERGED: the item's only counter lives in a register
         unsigned int nev = 0;              // band entries this lane evaluated
-        unsigned stage_no = 0;
-        auto flush = [&]() {  // LDS histogram -> global result (unweighted) / slab (weighted)
-            if (NF1 && !MERGED && !WEIGHTED) {
-                if (lane == 0 && cnt1) atomicAdd(&out_counts[(int64_t)islot * nslots], (unsigned long long)cnt1);  // every lane holds the wave total
-                cnt1 = 0;
-                return;
-            }
+        auto flush_slab = [&]() {  // weighted: LDS histogram -> the item's slab
             __syncthreads();
             for (int idx = lane; idx < nslots; idx += 64) {
-                HistT c = HistT(0);
+                double c = 0.0;
                 for (int h = 0; h < hp; ++h) {  // fixed order: reproducible weighted sums
-                    c += hist[idx * hp + h];
+                    c += (double)hist[idx * hp + h];
                     hist[idx * hp + h] = HistT(0);
                 }
-                if (WEIGHTED) partials[(int64_t)it.pot * nslots + idx] = (double)c;
-                else if (c != HistT(0)) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
+                partials[(int64_t)it.pot * nslots + idx] = c;
             }
         };
 
@@ -1212,6 +1236,46 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                 const double ez = lds_f64(a8 + (LDS_Z - LDS_X));
                 const double ew = WEIGHTED ? lds_f64(a8 - a_sx + a_sw) : 1.0;
                 const int ek = MERGED ? lds_i32(((a8 - a_sx) >> 1) + a_sx + (LDS_K - LDS_X)) : 0;
+                // edge row of the entry's bin and its outer edges: once per entry, not per evaluation, and without
+                // conditions around the reads (hipcc turned `a && b` over two LDS reads into exec branches with full waits)
+                const double *tk = thr + ((NEED_THR && !ROW1) ? ek * n_edges : 0);
+                const double t_first = (NEED_THR && !ROW1) ? tk[0] : e_lo, t_last = (NEED_THR && !ROW1) ? tk[n_edges - 1] : e_hi;
+                if constexpr (!REG_EDGES && !NF1) {
+                    // Many edges (separation weights: ~50 fine bins): the fine bins of the R evaluations are searched in
+                    // lockstep and for every lane -- R independent chains of LDS reads instead of one after the other under a
+                    // branch; a miss ends in some valid bin and goes to the dummy cell.
+                    double sdv[R];
+                    bool inv[R];
+                    int c[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double dx = ax[r] - ex, dy = ay[r] - ey, dz = az[r] - ez;
+                        const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                        const double sxy2 = xx + yy;
+                        sdv[r] = sxy2 + zz;
+                        inv[r] = (sdv[r] > t_first) & (sdv[r] <= t_last);
+                        c[r] = 0;
+                    }
+                    for (int step = edge_top; step > 0; step >>= 1) {  // fine bin = number of inner edges below s
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const int probe = c[r] + step;
+                            c[r] = sdv[r] > tk[probe < n_edges - 1 ? probe : n_edges - 1] ? probe : c[r];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const unsigned cell = ((unsigned)(ek * nf + c[r]) << ksh) + a_cell;  // t[c] < s <= t[c + 1]
+                        if constexpr (WEIGHTED) {
+                            if (inv[r])
+                                (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * ew,
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else {
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)(inv[r] ? cell : a_dummy),
+                                                         1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     double bx[R], by[R], bz[R], bw[R];
@@ -1231,15 +1295,12 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                         in = sd > ed[0] && sd <= ed[NE - 1];
                         if constexpr (NE >= 3) slot += (sd > ed[1]) ? 1 : 0;  // inner edges: t[c-1] < s <= t[c]
                         if constexpr (NE >= 4) slot += (sd > ed[2]) ? 1 : 0;
-                    } else if (thr_rows == 1) {
-                        in = sd > e_lo && sd <= e_hi;
                     } else {
-                        const double *tk = thr + kb[r] * n_edges;  // edge row of the entry's bin
-                        in = sd > tk[0] && sd <= tk[n_edges - 1];
+                        in = (sd > t_first) & (sd <= t_last);
                     }
                     if (NF1 && !MERGED && !WEIGHTED) {
                         cnt1 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(in));
-                    } else if (REG_EDGES && !WEIGHTED) {
+                    } else if ((REG_EDGES || NF1) && !WEIGHTED) {  // the slot is known without a search over the edges
                         // Branch-free: a miss adds to the lane's own dummy cell. (Under a branch the compiler can no longer
                         // count the LDS operations in flight and drains them all before every evaluation.)
                         const unsigned cell = in ? ((unsigned)slot << ksh) + a_cell : a_dummy;
@@ -1249,7 +1310,6 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                         if constexpr (!REG_EDGES) {
                             // fine bin = number of inner edges below s: a branch-free binary search over the sorted row
                             // (a probe past the inner edges reads the last edge, which s does not exceed)
-                            const double *tk = thr + (thr_rows == 1 ? 0 : kb[r] * n_edges);
                             int c = 0;
                             for (int step = edge_top; step > 0; step >>= 1) {
                                 const int probe = c + step;
@@ -1268,15 +1328,21 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
+                }
             }
             // 64*R lane objects x BCAP entries per stage: a uint32 counter cannot wrap within flush_mask + 1 stages
-            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush();
+            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush_counts(islot);
         }
         }
-        flush();
+        if (WEIGHTED) flush_slab();
         // evaluated band entries of the item -> one of EVAL_SLOTS counters (statistics)
         for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
         if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
+      }
+        if (!WEIGHTED && pend_slot >= 0) {  // end of the batch
+            flush_counts(pend_slot);
+            pend_slot = -1;
+        }
     }
 }
 
@@ -1395,6 +1461,7 @@ struct yawhip_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evc0 = nullptr, evc1 = nullptr;
     int tile_r = 0;          // 0 = auto
     int hist_copies_log2 = -1;  // band kernel: log2 of the copies of the LDS histogram (-1 = auto)
+    int band_batch_log2 = -1;   // band kernel: log2 of the consecutive items a workgroup takes per visit (-1 = auto)
     int band_cap = 0;        // entries per LDS stage of the band kernel: 0 = auto, BCAP (192), BCAP_MID (288)
     int seg_strips = 1;      // binned x binned counts of dense catalogues use the per-segment strip layouts
     int seg_min_run = SEG_STRIPS_MIN_RUN;  // mean run length of the lane side from which binned x binned counts use it
@@ -1930,6 +1997,11 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(YAWHIP_ERR_INVALID, "tile_r must be 0 (auto), 1, 2 or 4");
         ctx->tile_r = (int)value;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "band_batch_log2")) {
+        if (value < -1 || value > 6) return fail(YAWHIP_ERR_INVALID, "band_batch_log2 must be -1 (auto) or 0..6");
+        ctx->band_batch_log2 = (int)value;
         return YAWHIP_OK;
     }
     if (!strcmp(key, "hist_copies_log2")) {
@@ -2610,6 +2682,10 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
         // The strip builder keeps about one potential item in five, ordinary items are all kept.
         int64_t grid = strip_items && n_pot > 65536 ? n_pot / std::max(ctx->band_grid_div, 1) : n_pot;
+        // items per workgroup visit (unweighted): batches of 4 / 8 when the histogram has hundreds of cells to flush
+        const int n_cells = lean_bins * nf;
+        const int batch_log2 = ctx->band_batch_log2 >= 0 ? ctx->band_batch_log2 : (n_cells >= 512 ? 3 : (n_cells >= 128 ? 2 : 0));
+        if (!run_weighted) grid = std::max<int64_t>(grid >> batch_log2, 8);
         grid = std::min<int64_t>((grid + 7) & ~7ll, 1ll << 22);
         // 32-bit LDS counters: one stage adds at most 64 R x CAP to a cell, so flush at the latest every
         // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 192-entry stages, 2^15 for four and 288)
@@ -2626,7 +2702,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
-                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_rwin.ptr, flush_mask, hp_shift, ctx->d_counts.ptr,   \
+                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_rwin.ptr, flush_mask, hp_shift, WW ? 0 : batch_log2, ctx->d_counts.ptr, \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
 #define YAW_LAUNCH_BAND_R(WW, NN, MM, UU)                                                                             \
