@@ -1240,7 +1240,26 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                 // conditions around the reads (hipcc turned `a && b` over two LDS reads into exec branches with full waits)
                 const double *tk = thr + ((NEED_THR && !ROW1) ? ek * n_edges : 0);
                 const double t_first = (NEED_THR && !ROW1) ? tk[0] : e_lo, t_last = (NEED_THR && !ROW1) ? tk[n_edges - 1] : e_hi;
-                if constexpr (!REG_EDGES && !NF1) {
+                if constexpr (WEIGHTED && NF1 && R > 1) {
+                    // One fine bin: the R evaluations of an entry add to the same cell (the entry's bin), and neighbouring
+                    // objects mostly hit the same entries -- their products are summed in registers and go to the LDS as ONE
+                    // float64 atomic (those are slow: ~1 lane per cycle). Fixed order inside the lane: still reproducible.
+                    double acc = 0.0;
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double dx = ax[r] - ex, dy = ay[r] - ey, dz = az[r] - ez;
+                        const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                        const double sxy2 = xx + yy;
+                        const double sd = sxy2 + zz;
+                        const bool in = REG_EDGES ? (sd > ed[0]) & (sd <= ed[NE >= 2 ? NE - 1 : 0]) : (sd > t_first) & (sd <= t_last);
+                        acc += in ? aw[r] * ew : 0.0;
+                        any |= in;
+                    }
+                    if (any)
+                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)(((unsigned)ek << ksh) + a_cell), acc,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if constexpr (!REG_EDGES && !NF1) {
                     // Many edges (separation weights: ~50 fine bins): the fine bins of the R evaluations are searched in
                     // lockstep and for every lane -- R independent chains of LDS reads instead of one after the other under a
                     // branch; a miss ends in some valid bin and goes to the dummy cell.
