@@ -639,6 +639,35 @@ def test_weighted_shared_histogram_corner(ctx, kernel):
         np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
 
 
+def test_histogram_too_large_for_one_item_falls_back_to_per_bin_items(ctx):
+    """400 z-bins x 51 separation-weight bins, weighted: the all-bins-in-one-item histogram (163 KB) does not fit the LDS.
+    The count must fall back to (job, bin) items -- same results, ``layout_mode`` 0 -- instead of failing."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(77)
+    B = 400
+    c1 = _random_catalog(rng, 6000, 3, B, True, dense_box=1.0)
+    c2 = _random_catalog(rng, 5000, 3, 1, True, dense_box=1.0)
+    jobs = np.array([[0, 0], [0, 1], [1, 2], [2, 2]], dtype=np.int32)
+    lim = oracle.parse_ang_limits(np.array([0.5]) * np.pi / 10800, np.array([60.0]) * np.pi / 10800)
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, -1.0, 50)), (B, 1))
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    assert exp_c.sum() > 1e4
+    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+    for kernel in ("auto", "band", "sweep"):
+        counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel=kernel, want_counts=True, want_sums=True)
+        assert np.array_equal(counts, exp_c), kernel
+        np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+        assert st.layout_mode == 0
+    # with a quarter of the bins the merged item fits again
+    t4 = t[: B // 4]
+    c1b = _random_catalog(rng, 6000, 3, B // 4, True, dense_box=1.0)
+    exp_c, exp_s = oracle.count_jobs(c1b, c2, jobs, t4)
+    counts, sums, st = _lib.count_pairs(ctx, _upload(ctx, c1b), d2, jobs, t4, kernel="auto", want_counts=True, want_sums=True)
+    assert np.array_equal(counts, exp_c) and st.layout_mode == 1
+    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+
+
 def test_counts_beyond_32_bits_per_item(ctx):
     """More than 2^32 pairs in ONE (work item, fine bin): 4.3 M streamed objects against a tile of 1024 lane objects,
     all inside one wide bin. The 32-bit LDS counters are moved to the 64-bit result before they wrap."""

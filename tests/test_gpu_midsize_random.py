@@ -60,9 +60,11 @@ def test_culling_paths_equal_brute_force(ctx, seed):
     n_scales = int(rng.integers(1, 4))
     lo = np.sort(rng.uniform(0.002, 0.02, n_scales)) * cap
     hi = lo * rng.uniform(2.0, 8.0, n_scales)
-    t_row = oracle.thresholds_for(oracle.ang_bins_for(oracle.parse_ang_limits(lo, hi), None, None))
+    # one in three: separation weights, i.e. dozens of fine bins per z-bin (edge table in LDS, fine bin by binary search)
+    rw, res = (-1.0, int(rng.integers(5, 60))) if rng.integers(0, 3) == 0 else (None, None)
+    t_row = oracle.thresholds_for(oracle.ang_bins_for(oracle.parse_ang_limits(lo, hi), rw, res))
     t = np.stack([t_row] * B) if rng.integers(0, 2) else np.stack(
-        [oracle.thresholds_for(oracle.ang_bins_for(oracle.parse_ang_limits(lo * (1 + 0.05 * k), hi * (1 + 0.05 * k)), None, None))
+        [oracle.thresholds_for(oracle.ang_bins_for(oracle.parse_ang_limits(lo * (1 + 0.05 * k), hi * (1 + 0.05 * k)), rw, res))
          for k in range(B)])
     jobs = np.array([(p, q) for p in range(P) for q in range(P) if rng.random() < 0.7 or p == q], dtype=np.int32)
     micro = int(max(1000, np.ceil(1.02e6 * np.sqrt(t.max()) / 50) * 50)) if rng.integers(0, 4) else 0

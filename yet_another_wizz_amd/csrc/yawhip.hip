@@ -2325,7 +2325,16 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         const int64_t seg_runs = base2.h_vbase[(size_t)base2.n_groups] * (int64_t)c2->nb;
         seg_ok = c2->n / std::max<int64_t>(seg_runs, 1) >= ctx->seg_min_run;
     }
-    const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? 1 : (seg_ok ? 3 : 0);
+    bool uniform_t = true;  // every bin has the same threshold row (angular scales)
+    for (int k = 1; k < n_bins && uniform_t; ++k)
+        uniform_t = memcmp(t, t + (size_t)k * n_edges, sizeof(double) * n_edges) == 0;
+    // One item for all bins needs a histogram of B x (E - 1) cells (and B edge rows when they differ) in LDS. Where that
+    // does not fit (hundreds of bins times dozens of separation-weight bins), the count falls back to ordinary
+    // (job, bin) items, whose histogram has E - 1 cells.
+    const size_t merged_lds = (size_t)n_bins * nf * (weighted_any ? 8 : 4) + (size_t)(uniform_t ? 1 : n_bins) * n_edges * sizeof(double) +
+                              (size_t)n_bins * sizeof(float) + BandLds<BCAP_MID>::FIXED + (BCAP_MID + 2) * 8 + 2 * MSTAGE * sizeof(ObjF) + 1024;
+    const bool merged_fits = merged_lds <= (size_t)ctx->lds_limit;
+    const int mode = !strips ? 0 : (c1->nb > 1 && c2->nb == 1) ? (merged_fits ? 1 : 0) : (seg_ok ? 3 : 0);
     const bool merged = mode == 1;                // one item covers all bins, output slot = job
     const bool strip_items = mode != 0;           // items come from strip runs (k_build_items_strips)
     // Orientation of every job: the (u, v) projection that compresses the sphere least around its two patches, i.e.
@@ -2433,9 +2442,6 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
                               (size_t)lean_bins * nf * (weighted_any ? 8 * (MWG / 64) : 4) + (size_t)lean_bins * sizeof(float) +
                               (size_t)MWG * sizeof(unsigned int) + 16;
-    bool uniform_t = true;  // every bin has the same threshold row (angular scales)
-    for (int k = 1; k < n_bins && uniform_t; ++k)
-        uniform_t = memcmp(t, t + (size_t)k * n_edges, sizeof(double) * n_edges) == 0;
     // Copies of the LDS histogram, lanes spread over them by lane id: same-address atomics of one instruction are
     // serialised. Four copies when there are few slots and the bins of neighbouring entries are unrelated (headline:
     // 0.535 ms with four, 0.565 with eight -- the flush grows with the copies). When the histogram has only the fine bins
@@ -2456,8 +2462,12 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     if (ctx->hist_copies_log2 >= 0) hp_shift = ctx->hist_copies_log2;
     const int band_ne = (!merged || uniform_t) && n_edges <= 4 ? n_edges : (nf == 1 ? 2 : 0);  // compile-time edge count of k_count_band
     const bool band_thr = !(band_ne >= 2 && (!merged || uniform_t));
-    const size_t lds_band = band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << hp_shift, cap, merged && !uniform_t ? lean_bins : 1);
     const size_t LDS_FIXED = (size_t)band_lds_fixed(cap);
+    auto band_lds_for = [&](int shift) {
+        return band_lds_dynamic(weighted_any, band_thr, lean_bins, n_edges, 1 << shift, cap, merged && !uniform_t ? lean_bins : 1);
+    };
+    while (band && hp_shift > 0 && band_lds_for(hp_shift) + LDS_FIXED > (size_t)ctx->lds_limit) --hp_shift;  // copies are a tunable, not a need
+    const size_t lds_band = band_lds_for(hp_shift);
     if (lean && (band ? lds_band + LDS_FIXED : lds_merged) > (size_t)ctx->lds_limit)
         return fail(YAWHIP_ERR_INVALID, "too many bins x edges for the LDS histogram (%zu bytes)", band ? lds_band + LDS_FIXED : lds_merged);
 
