@@ -36,7 +36,7 @@ def _sample(rng, n, cap, clumps, frac, P, nb, weighted, centres):
     return oracle.sort_catalog(ra, dec, z, w, patch, P, edges, "right")
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(40))
 def test_culling_paths_equal_brute_force(ctx, seed):
     from yet_another_wizz_amd import _lib
 
@@ -67,7 +67,9 @@ def test_culling_paths_equal_brute_force(ctx, seed):
         [oracle.thresholds_for(oracle.ang_bins_for(oracle.parse_ang_limits(lo * (1 + 0.05 * k), hi * (1 + 0.05 * k)), rw, res))
          for k in range(B)])
     jobs = np.array([(p, q) for p in range(P) for q in range(P) if rng.random() < 0.7 or p == q], dtype=np.int32)
-    micro = int(max(1000, np.ceil(1.02e6 * np.sqrt(t.max()) / 50) * 50)) if rng.integers(0, 4) else 0
+    micro = int(max(1000, np.ceil(1.02e6 * np.sqrt(t.max()) / 50) * 50))  # just above the largest chord: three partner strips
+    # also: no strips; narrower strips (five to nine partner strips, several windows groups per tile); wider ones
+    micro = int(rng.choice([micro, micro, 0, max(1000, int(micro / 2.7)), max(1000, int(micro / 3.9)), min(3 * micro, 2000000)]))
     axis = int(rng.integers(0, 3))
     try:
         ctx.set_option("strip_width_micro", micro)
