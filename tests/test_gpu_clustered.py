@@ -94,3 +94,30 @@ def test_auto_counts_match_the_reference_exactly(setup, kernel):
     got = np.stack([r.counts.counts for r in res])
     assert np.array_equal(got, g["auto_counts"])
     assert float(got.sum()) > 5e9  # billions of pairs: dense clumps, long bands
+
+
+def test_full_measurement_physical_scales_separation_weights_randoms():
+    """A complete ``crosscorrelate`` at mid size on the clustered survey, as a user of the reference would run it:
+    physical scales 150-1500 kpc (every z-bin its own thresholds), ``rweight=-1`` with 30 log bins (31 fine bins per
+    z-bin), weighted unknown sample, two random samples -> DD, DR, RD, RR tensors, patch sums and ``CorrFunc.sample()``
+    (w(z), jackknife samples, errors, covariance) against the reference's own outputs
+    (tools/make_golden_clustered.py --full; D_A(z) of the reference's cosmology stand-in is this package's)."""
+    import yet_another_wizz_amd as yaw
+    from helpers import check_corrfuncs
+    from make_golden_clustered_params import FULL
+
+    g = np.load(os.path.join(GOLDEN, "clustered_reference_full.npz"))
+    centers = yaw.AngularCoordinates(cs.patch_centers())
+
+    def cat(seed, n, frac, with_z, with_w):
+        c = cs.sample(seed, int(n), clustered_fraction=frac, with_z=with_z, with_w=with_w)
+        return yaw.Catalog.from_arrays(c["ra"], c["dec"], redshifts=c.get("z"), weights=c.get("w"), patch_centers=centers,
+                                       degrees=False)
+
+    ref, unk = cat(101, FULL["n_ref"], 0.7, True, False), cat(202, FULL["n_unk"], 0.7, False, True)
+    ref_rand, unk_rand = cat(303, FULL["n_ref_rand"], 0.0, True, False), cat(404, FULL["n_unk_rand"], 0.0, False, True)
+    config = yaw.Configuration.create(rmin=FULL["rmin"], rmax=FULL["rmax"], unit=FULL["unit"], rweight=FULL["rweight"],
+                                      resolution=FULL["resolution"], edges=cs.bin_edges())
+    cfs = yaw.crosscorrelate(config, ref, unk, ref_rand=ref_rand, unk_rand=unk_rand)
+    check_corrfuncs("cross", cfs, g, exact=lambda kind: False)
+    assert np.all(np.isfinite(cfs[0].sample().data)) and cfs[0].sample().data.max() > 50  # a strongly clustered sample

@@ -24,6 +24,51 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+from make_golden_clustered_params import FULL  # tests/: shared with the GPU test
+
+
+def make_full(args, yaw, cs, out_path):
+    """A complete measurement at mid size on the clustered survey: crosscorrelate with both random samples (DD, DR, RD,
+    RR), physical scales (every z-bin its own thresholds), separation weights (31 fine bins per z-bin), weighted unknown
+    sample and weighted randoms -> count tensors, patch sums and CorrFunc.sample() of the reference."""
+    import pandas as pd
+    from make_golden import dump_counts
+    from yaw.coordinates import AngularCoordinates
+
+    centers = AngularCoordinates(cs.patch_centers())
+    shutil.rmtree(args.cache, ignore_errors=True)
+    os.makedirs(args.cache)
+
+    def cat(name, seed, n, frac, with_z, with_w):
+        cols = cs.sample(seed, int(n), clustered_fraction=frac, with_z=with_z, with_w=with_w)
+        return yaw.Catalog.from_dataframe(os.path.join(args.cache, name), pd.DataFrame(cols), ra_name="ra", dec_name="dec",
+                                          redshift_name="z" if with_z else None, weight_name="w" if with_w else None,
+                                          patch_centers=centers, degrees=False)
+
+    ref = cat("ref", 101, FULL["n_ref"], 0.7, True, False)
+    unk = cat("unk", 202, FULL["n_unk"], 0.7, False, True)
+    ref_rand = cat("ref_rand", 303, FULL["n_ref_rand"], 0.0, True, False)
+    unk_rand = cat("unk_rand", 404, FULL["n_unk_rand"], 0.0, False, True)
+    config = yaw.Configuration.create(rmin=FULL["rmin"], rmax=FULL["rmax"], unit=FULL["unit"], rweight=FULL["rweight"],
+                                      resolution=FULL["resolution"], edges=cs.bin_edges())
+    # astropy is absent here: the reference's Planck15 stand-in (tools/ref_loader.py, SURVEY.md Appendix A) gets its
+    # D_A(z) from this package's flat-LCDM (itself pinned by the reference's estimate.dat); everything downstream --
+    # scale / D_A, edges, thresholds, counts, estimator -- is the reference's own code (cosmology.py:250-259).
+    from yet_another_wizz_amd.cosmology import get_default_cosmology
+
+    ours = get_default_cosmology()
+    type(config.cosmology).angular_diameter_distance = lambda self, z: ours.angular_diameter_distance(z)
+    t0 = time.perf_counter()
+    cfs = yaw.crosscorrelate(config, ref, unk, ref_rand=ref_rand, unk_rand=unk_rand, max_workers=args.workers)
+    secs = time.perf_counter() - t0
+    out = {"seconds": secs}
+    dump_counts("cross", cfs, out)
+    print(f"crosscorrelate (DD, DR, RD, RR): {secs:.1f} s; w(z) = {cfs[0].sample().data}", flush=True)
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, os.path.getsize(out_path), "bytes")
+    shutil.rmtree(args.cache, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n-ref", type=float, default=1.5e6)
@@ -32,11 +77,16 @@ def main():
     ap.add_argument("--exact-slots", type=int, default=12, help="largest slots of the cross count to recompute exactly")
     ap.add_argument("--cache", default="/dev/shm/yaw_ref_clustered")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "clustered_reference_counts.npz"))
+    ap.add_argument("--full", action="store_true", help="the complete mid-size measurement instead (clustered_reference_full.npz)")
     args = ap.parse_args()
     os.environ["YAW_NUM_THREADS"] = str(args.workers)
     from ref_loader import load_reference
 
     yaw = load_reference(args.workers)
+    if args.full:
+        import clustered_sky
+
+        return make_full(args, yaw, clustered_sky, os.path.join(ROOT, "tests", "golden", "clustered_reference_full.npz"))
     import pandas as pd
     import scipy
     from yaw.coordinates import AngularCoordinates
