@@ -121,3 +121,5 @@ def test_full_measurement_physical_scales_separation_weights_randoms():
     cfs = yaw.crosscorrelate(config, ref, unk, ref_rand=ref_rand, unk_rand=unk_rand)
     check_corrfuncs("cross", cfs, g, exact=lambda kind: False)
     assert np.all(np.isfinite(cfs[0].sample().data)) and cfs[0].sample().data.max() > 50  # a strongly clustered sample
+    # and the autocorrelation of the reference sample against its randoms (binned x binned: DD, DR, RR)
+    check_corrfuncs("auto", yaw.autocorrelate(config, ref, ref_rand), g, exact=lambda kind: False)

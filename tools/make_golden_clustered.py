@@ -64,6 +64,11 @@ def make_full(args, yaw, cs, out_path):
     out = {"seconds": secs}
     dump_counts("cross", cfs, out)
     print(f"crosscorrelate (DD, DR, RD, RR): {secs:.1f} s; w(z) = {cfs[0].sample().data}", flush=True)
+    t0 = time.perf_counter()
+    acfs = yaw.autocorrelate(config, ref, ref_rand, max_workers=args.workers)  # binned x binned: DD, DR, RR
+    out["auto_seconds"] = time.perf_counter() - t0
+    dump_counts("auto", acfs, out)
+    print(f"autocorrelate (DD, DR, RR): {out['auto_seconds']:.1f} s; w(z) = {acfs[0].sample().data}", flush=True)
     np.savez_compressed(out_path, **out)
     print("wrote", out_path, os.path.getsize(out_path), "bytes")
     shutil.rmtree(args.cache, ignore_errors=True)
