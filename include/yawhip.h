@@ -92,7 +92,7 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
 /* Tunables (all optional):
  *   "tile_r"            objects per lane (0 = auto, 1, 2, 4)
  *   "band_batch_log2"   band kernel: log2 of the consecutive items a workgroup takes per visit, carrying its unweighted
- *                       histogram while they add to the same output slot (-1 = auto: 1 item, 4 / 8 with >= 128 / 512 cells)
+ *                       histogram while they add to the same output slot (-1 = default: 1 item; larger batches unbalance clustered data)
  *   "hist_copies_log2"  band kernel: log2 of the copies of its LDS histogram (-1 = auto: 4 copies for few slots, up to 16
  *                       for per-bin items or when neighbouring objects of a binned catalogue mostly share their bin; 0..6)
  *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 192, or 288 when a lane tile's window is
