@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--workers", type=int, nargs="+", default=[8, 1])
     ap.add_argument("--cache", default="/dev/shm/yaw_ref_timing")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--slots-out", default=None,
+                    help="write the reference's per-slot values counts[s][:, i, j] of every --slot-every'th linked patch "
+                         "pair (and the patch ids) to this .npz: the full-size parity fixtures of tests/golden/")
+    ap.add_argument("--slot-every", type=int, default=1)
     args = ap.parse_args()
 
     os.environ["YAW_NUM_THREADS"] = str(max(args.workers))
@@ -100,6 +104,7 @@ def main():
 
     runs = []
     totals = {}
+    slots = {}
     for w in args.workers:
         for name, cats in passes:
             t0 = time.perf_counter()
@@ -109,6 +114,14 @@ def main():
             found = float(per_scale_bin.sum())
             if name not in totals:
                 totals[name] = per_scale_bin
+                if args.slots_out:
+                    # jobs of this count as the reference lists them (measurements.py:258-289), every n-th kept
+                    ids = np.array(list(links.iter_patch_id_pairs(auto=len(cats) == 1)), dtype=np.int32)[:: args.slot_every]
+                    vals = np.stack([r.counts.counts[:, ids[:, 0], ids[:, 1]] for r in res])  # [S, B, n_sel]
+                    slots[name + "_ids"] = ids
+                    slots[name + "_values"] = np.ascontiguousarray(np.moveaxis(vals, 2, 0))   # [n_sel, S, B]
+                    slots[name + "_sum_weights1"] = res[0].sum_weights.sum_weights1
+                    slots[name + "_sum_weights2"] = res[0].sum_weights.sum_weights2
             assert np.allclose(per_scale_bin, totals[name], rtol=1e-12, atol=0)
             run = dict(count=name, workers=w, seconds=secs, found_pairs_per_s=found / secs)
             if not auto:
@@ -135,6 +148,10 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump(out, f, indent=1)
+    if args.slots_out:
+        np.savez_compressed(args.slots_out, n_ref=n_ref, n_unk=n_rand if auto else n_unk, patches=args.patches,
+                            z_bins=args.zbins, scales=args.scales, weighted=bool(args.weights), slot_every=args.slot_every,
+                            candidate_pairs=cand, **slots)
     shutil.rmtree(args.cache, ignore_errors=True)
 
 

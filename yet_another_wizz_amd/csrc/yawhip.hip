@@ -140,12 +140,16 @@ __host__ __device__ inline int item_orient(const Item &it) { return (int)((unsig
 typedef const __attribute__((address_space(1))) double *gf64p;
 typedef const __attribute__((address_space(1))) int32_t *gi32p;
 typedef const __attribute__((address_space(1))) int64_t *gi64p;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4 *gq4p;
 struct DevTab {
     gf64p x, y, z, w;          // columns; w may be null
     gi32p k;                   // bin id per object (merged cross-correlation layouts), else null
     gi64p off;                 // run offsets [V+1] (strip layouts) or segment offsets
     gi64p vbase, slo, tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
     gi32p tile_run;            // strip layouts: run of every lane tile
+    gq4p q;                    // strip layouts: float32 image {x, y, z, bin id} of every object (k_count_band32)
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
 __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *__restrict__ tabs, const int32_t *__restrict__ jobs,
                                                             const int32_t *__restrict__ job_runs,
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
-                                                            int tile, double rwin, int64_t n_pot,
+                                                            int tile, double rwin, int swap, int64_t n_pot,
                                                             Item *__restrict__ items, unsigned long long *__restrict__ counters,
                                                             unsigned char *__restrict__ kept) {
     const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,9 +294,10 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
                 if (prefix[mid] <= pot) lo = mid; else hi = mid;
             }
         }
-        const int job = lo, p = jobs[2 * job], q = jobs[2 * job + 1];
+        // swap: the lane tiles come from the first catalogue of the job (the binned one), the windows from the second
+        const int job = lo, p = jobs[2 * job + swap], q = jobs[2 * job + 1 - swap];
         const int o = job_runs[3 * job + 2];  // orientation of the job: which pair of layouts it runs on
-        const DevTab &c1 = tabs[o], &c2 = tabs[3 + o];
+        const DevTab &c1 = tabs[swap ? 3 + o : o], &c2 = tabs[swap ? o : 3 + o];
         const gf64p key1 = tab_key(c1), key2 = tab_key(c2);
         // potential items of a job, in this order: run of patch q, group of neighbour offsets, lane tile of the run. One
         // item carries up to MAX_WIN neighbouring strips of patch p (all 2 * reach + 1 = 3 of them when the grid is as
@@ -1364,6 +1369,311 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Band kernel, float32 classification (BAND on strip layouts of unit vectors).
+// Same items and the same walk as k_count_band, but an entry is decided in FLOAT32 wherever float32 can decide it:
+//   * both catalogues keep a float32 image of every strip layout, 16 bytes per object {x, y, z, bin id} (DevTab::q);
+//     the window is staged from it by LDS-DMA (one dwordx4 per entry) and read back with one ds_read_b128;
+//   * s32 = fma(dz, dz, fma(dy, dy, dx * dx)) on the float32 images, two lane objects per packed instruction
+//     (v_pk_add / v_pk_mul / v_pk_fma_f32: 7 VALU for two evaluations instead of 16 FP64 operations);
+//   * for unit vectors |s32 - s| <= g(t) = 4.2e-7 sqrt(t) + 5e-7 t + 1e-12 around an edge t (rounding of the images to
+//     float32: 2^-24 per coordinate; of the differences; of the three-term sum), so s32 < t - g proves s <= t and
+//     s32 > t + g proves s > t. The host turns every edge into the two float32 bounds (thr32, build_thr32);
+//   * an evaluation that lands inside a guard band (~1e-4 of them at the headline) is UNCERTAIN: the wave branches, the
+//     lanes concerned fetch both objects in float64 and apply the exact predicate of the parity contract
+//     (((dx*dx + dy*dy) + dz*dz) against the host's float64 thresholds). Every pair is therefore decided exactly as
+//     k_count_band decides it: results are bit-identical.
+// The roles are swapped against k_count_band where one side is binned (MERGED, the cross-correlation counts): the
+// lanes hold the BINNED objects (c1), the window streams the unbinned side (c2). A lane then knows the bin, the edge
+// row and the counter of each of its objects: hits are counted in registers (add with carry) and go to the LDS
+// histogram once per item, not once per evaluation.
+//   NE == 2 (one annulus): classes by |s32 - c| against two half widths (certainly inside / possibly inside);
+//   NE  > 2: cumulative counters per edge (s <= t_e), fine bin j = cum[j + 1] - cum[j] at the flush.
+// ------------------------------------------------------------------------------------------------
+constexpr float PAD_COORD32 = 4.0f;
+// float32 words per bin of the threshold table: NE == 2: {c, h_in, h_out, 0}; else per edge {t - g, t + g}
+__host__ __device__ constexpr int thr32_width(int ne) { return ne == 2 ? 4 : 2 * ne; }
+// dynamic LDS of a k_count_band32 workgroup (host and device agree through this one function)
+__host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots, int thr_rows, int ne) {
+    return (size_t)(cap + 1) * 16 + (weighted ? (size_t)(cap + 2) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) +
+           (size_t)thr_rows * thr32_width(ne) * 4 + 32;
+}
+
+template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
+__global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+                                                     const double *__restrict__ t, const float *__restrict__ thr32,
+                                                     const double *__restrict__ rwin_k, unsigned flush_mask,
+                                                     unsigned long long *__restrict__ out_counts,
+                                                     double *__restrict__ partials,
+                                                     unsigned long long *__restrict__ counters) {
+    static_assert(NE >= 2 && NE <= 4, "edges per bin");
+    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
+    constexpr int NC = NE == 2 ? 1 : NE;     // counters per lane object: hits of the annulus, or s <= t_e per edge
+    constexpr int NF = NE - 1;               // fine bins per redshift bin
+    constexpr int TW = thr32_width(NE);
+    constexpr bool LANE_THR = MERGED && !UNI;  // every lane object has the edge row of its own bin
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    const int nkb = MERGED ? n_bins : 1;
+    const int nslots = nkb * NF;
+    unsigned char *p = lds_dyn;
+    f32x4 *stage = reinterpret_cast<f32x4 *>(p); p += (size_t)(CAP + 1) * 16;
+    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 2) * 8;
+    HistT *hist = reinterpret_cast<HistT *>(p); p += (size_t)nslots * sizeof(HistT);
+    p = reinterpret_cast<unsigned char *>(((size_t)p + 15) & ~(size_t)15);
+    float *sthr = reinterpret_cast<float *>(p);  // [n_bins][TW] when LANE_THR
+    const int lane = threadIdx.x;
+    const unsigned a_stage = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(stage);
+    const unsigned a_sw = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
+    const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
+
+    const unsigned long long n_kept = counters[0];
+    const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
+    if (LANE_THR)
+        for (int e = lane; e < n_bins * TW; e += 64) sthr[e] = thr32[e];
+    unsigned stage_no = 0;
+    for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
+        if ((v >> 3) >= chunk) break;
+        const unsigned long long ticket = (v & 7) * chunk + (v >> 3);
+        if (ticket >= n_kept) continue;  // short last eighth
+        const Item it = items[ticket];
+        const int o = item_orient(it), islot = item_slot(it);
+        const DevTab cl = tabs[MERGED ? o : 3 + o], cs = tabs[MERGED ? 3 + o : o];  // lane side, streamed side
+        const int kfix = MERGED ? 0 : islot % n_bins;
+        // half width of the u-window in float32: sqrt(t_max) widened by the rounding of both keys and of the subtraction
+        const float rwin = (float)(rwin_k[kfix] * 1.000001 + 4e-7);
+        int64_t b0 = it.b0[0], nb_total = it.nb[0];
+
+        __syncthreads();  // the previous item of this workgroup has left the LDS
+        auto stage_in = [&](int64_t first, int n) {
+            const gq4p gq = cs.q + b0 + first;
+#pragma unroll
+            for (int c = 0; c < (CAP + 63) / 64; ++c) {
+                const unsigned e = (unsigned)(c * 64 + lane);
+                if (e < (unsigned)n) __builtin_amdgcn_global_load_lds(gq + e, lds_ptr(a_stage + c * 1024), 16, 0, 0);
+            }
+            if (WEIGHTED && cs.w) {
+#pragma unroll
+                for (int c = 0; c < (CAP + 127) / 128; ++c) {
+                    const unsigned e = (unsigned)(c * 128 + 2 * lane);
+                    if (e < (unsigned)n) __builtin_amdgcn_global_load_lds(cs.w + b0 + first + e, lds_ptr(a_sw + c * 1024), 16, 0, 0);
+                }
+            }
+        };
+        stage_in(0, (int)(nb_total < CAP ? nb_total : CAP));
+        // lane objects while the stage is in flight: R NEIGHBOURING objects of the u-sorted tile per lane
+        f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
+        float ax[R], ay[R], az[R];
+        double aw[R];
+        int kb[R];
+        int n_own = (int)it.na - lane * R;
+        n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool have = r < n_own;
+            const unsigned ic = have ? (unsigned)(lane * R + r) : 0u;
+            const f32x4 q = (cl.q + it.a0)[ic];
+            ax[r] = have ? q.x : PAD_COORD32; ay[r] = have ? q.y : PAD_COORD32; az[r] = have ? q.z : PAD_COORD32;
+            const float qw = q.w;  // (a bit cast of the vector element itself read element 0)
+            kb[r] = MERGED ? (have ? __float_as_int(qw) : 0) : 0;
+            aw[r] = (WEIGHTED && cl.w) ? (have ? (cl.w + it.a0)[ic] : 0.0) : (have ? 1.0 : 0.0);
+        }
+        // thresholds: per lane object (its bin's row from the LDS table) or one row for the wave
+        float th[R][TW];
+        {
+            const float *row = LANE_THR ? nullptr : thr32 + (size_t)kfix * TW;  // uniform: scalar loads
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int q = 0; q < TW; ++q) th[r][q] = LANE_THR ? sthr[kb[r] * TW + q] : row[q];
+        }
+        float klo, khi;
+        {
+            const int last_r = n_own > 0 ? n_own - 1 : 0;
+            float u_first = cl.axis == 0 ? ax[0] : (cl.axis == 1 ? ay[0] : az[0]), u_last = u_first;
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                if (r == last_r) u_last = cl.axis == 0 ? ax[r] : (cl.axis == 1 ? ay[r] : az[r]);
+            klo = u_first - rwin;
+            khi = u_last + rwin;
+        }
+        if constexpr (R >= 2) {
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                ax2[h] = f32x2{ax[2 * h], ax[2 * h + 1]}; ay2[h] = f32x2{ay[2 * h], ay[2 * h + 1]}; az2[h] = f32x2{az[2 * h], az[2 * h + 1]};
+            }
+        }
+        unsigned int cnt[R][NC];
+        double acc[R][NC];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { cnt[r][c] = 0u; acc[r][c] = 0.0; }
+        unsigned int nev = 0;
+        // lane counters -> LDS histogram (cell = bin of the object x fine bin)
+        auto flush_lanes = [&]() {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const unsigned cell = a_hist + (unsigned)((kb[r] * NF + f) * (int)sizeof(HistT));
+                    if constexpr (WEIGHTED) {
+                        const double vsum = NE == 2 ? acc[r][0] : acc[r][f + 1] - acc[r][f];
+                        // float64 adds of ONE instruction that hit the same cell are serialised by the LDS in a fixed lane
+                        // order; the histogram belongs to this wave alone -> reproducible sums
+                        if (vsum != 0.0)
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * vsum,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        const unsigned int c = NE == 2 ? cnt[r][0] : cnt[r][f + 1] - cnt[r][f];
+                        if (c)
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, c,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { cnt[r][c] = 0u; acc[r][c] = 0.0; }
+            }
+        };
+        auto flush_counts = [&]() {  // LDS histogram -> global result (unweighted)
+            flush_lanes();
+            __syncthreads();
+            for (int idx = lane; idx < nslots; idx += 64) {
+                const unsigned int c = (unsigned int)hist[idx];
+                hist[idx] = HistT(0);
+                if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
+            }
+        };
+
+        for (int win = 0; win < it.nwin; ++win) {
+        if (win > 0) {
+            b0 = win == 1 ? it.b0[1] : it.b0[2];
+            nb_total = win == 1 ? it.nb[1] : it.nb[2];
+        }
+        for (int64_t st0 = 0; st0 < nb_total; st0 += CAP, ++stage_no) {
+            const int n = (int)(nb_total - st0 < CAP ? nb_total - st0 : CAP);
+            if (st0 > 0 || win > 0) {
+                __syncthreads();  // every lane is done with the previous stage
+                stage_in(st0, n);
+            }
+            __syncthreads();  // the stage has landed (the compiler drains the LDS-DMA in front of the barrier)
+            if (lane == 0) {  // sentinel behind the stage: beyond every edge of every lane object
+                stage[n] = f32x4{PAD_COORD32, PAD_COORD32, PAD_COORD32, 0.f};
+                if (WEIGHTED) sw[n] = 0.0;
+            }
+            if (WEIGHTED && !cs.w)
+                for (int e = lane; e < n; e += 64) sw[e] = 1.0;
+            __syncthreads();
+            // band of the lane inside this stage: [lo, hi) = entries with klo <= key <= khi, by two branch-free binary
+            // searches on LDS byte addresses (q = address of entry lo - 1; a probe beyond the stage is clamped onto the
+            // sentinel, whose key 4.0 fails both comparisons)
+            const unsigned a_key = a_stage + 4u * (unsigned)cl.axis;
+            const unsigned a_sent = a_key + ((unsigned)n << 4);
+            unsigned ql = a_key - 16u, qh = ql;
+            for (unsigned step = 16u << (31 - __builtin_clz(n)); step >= 16u; step >>= 1) {  // largest power of two <= n
+                const unsigned pl = ql + step, ph = qh + step;
+                const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent ? pl : a_sent);
+                const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent ? ph : a_sent);
+                ql = kl < klo ? pl : ql;    // entries [0, lo) have key <  klo
+                qh = kh <= khi ? ph : qh;   // entries [0, hi) have key <= khi
+            }
+            int lo = (int)((ql + 16u - a_key) >> 4), hi = (int)((qh + 16u - a_key) >> 4);
+            if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
+            const int len = hi - lo;
+            nev += (unsigned int)(len * n_own);
+            const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
+
+            unsigned cur = a_stage + ((unsigned)lo << 4);
+            const unsigned last = a_stage + ((unsigned)n << 4);
+            for (int s = 0; s < steps; ++s) {
+                const unsigned a16 = cur < last ? cur : last;
+                cur += 16;
+                const f32x4 en = *(const __attribute__((address_space(3))) f32x4 *)(size_t)a16;
+                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) >> 1) + a_sw) : 1.0;
+                float s32[R];
+                if constexpr (R >= 2) {
+#pragma unroll
+                    for (int h = 0; h < R / 2; ++h) {
+                        const f32x2 dx = ax2[h] - en.x, dy = ay2[h] - en.y, dz = az2[h] - en.z;
+                        const f32x2 sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                        s32[2 * h] = sq.x; s32[2 * h + 1] = sq.y;
+                    }
+                } else {
+                    const float dx = ax[0] - en.x, dy = ay[0] - en.y, dz = az[0] - en.z;
+                    s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                }
+                // classes as wave masks: "certainly inside / below" feeds the lane counters (add with carry), "possibly" stays
+                // on the scalar unit -- undecided = possibly & ~certainly costs no vector instruction
+                unsigned long long unc_mask[R];
+                unsigned long long any_mask = 0ull;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if constexpr (NE == 2) {
+                        const float q = __builtin_fabsf(s32[r] - th[r][0]);
+                        const bool in = q < th[r][1];
+                        unc_mask[r] = __builtin_amdgcn_ballot_w64(q < th[r][2]) & ~__builtin_amdgcn_ballot_w64(in);
+                        if constexpr (WEIGHTED) acc[r][0] += in ? ew : 0.0;
+                        else cnt[r][0] += in ? 1u : 0u;
+                    } else {
+                        unc_mask[r] = 0ull;
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) {
+                            const bool le = s32[r] < th[r][2 * e];  // certainly s <= t_e
+                            unc_mask[r] |= __builtin_amdgcn_ballot_w64(s32[r] <= th[r][2 * e + 1]) & ~__builtin_amdgcn_ballot_w64(le);
+                            if constexpr (WEIGHTED) acc[r][e] += le ? ew : 0.0;
+                            else cnt[r][e] += le ? 1u : 0u;
+                        }
+                    }
+                    any_mask |= unc_mask[r];
+                }
+                if (any_mask != 0ull) {
+                    // inside a guard band: the exact float64 predicate on the float64 columns decides (rare)
+                    const unsigned eidx = (a16 - a_stage) >> 4;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
+                            const int64_t gi = b0 + st0 + eidx, li = it.a0 + lane * R + r;
+                            const double dx = cl.x[li] - cs.x[gi], dy = cl.y[li] - cs.y[gi], dz = cl.z[li] - cs.z[gi];
+                            const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                            const double sxy = xx + yy;
+                            const double sd = sxy + zz;
+                            const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
+                            if constexpr (NE == 2) {
+                                const bool in = sd > tk[0] && sd <= tk[1];
+                                if constexpr (WEIGHTED) acc[r][0] += in ? ew : 0.0;
+                                else cnt[r][0] += in ? 1u : 0u;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < NE; ++e) {
+                                    const bool open = !(s32[r] < th[r][2 * e]) && s32[r] <= th[r][2 * e + 1];  // this edge was left undecided
+                                    const bool le = open && sd <= tk[e];
+                                    if constexpr (WEIGHTED) acc[r][e] += le ? ew : 0.0;
+                                    else cnt[r][e] += le ? 1u : 0u;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // a lane counter grows by at most one per trip, the LDS cell by 64 R per trip: flush before 2^32
+            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush_counts();
+        }
+        }
+        if constexpr (WEIGHTED) {
+            flush_lanes();
+            __syncthreads();
+            for (int idx = lane; idx < nslots; idx += 64) {
+                partials[(int64_t)it.pot * nslots + idx] = (double)hist[idx];
+                hist[idx] = HistT(0);
+            }
+        } else {
+            flush_counts();
+        }
+        for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
+        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
+    }
+}
+
 // Evaluated pairs per job (na * nb of the job's kept items): the cost the host balances over GPUs.
 __global__ void k_item_work(const Item *__restrict__ items, const unsigned long long *__restrict__ counters,
                             int slots_per_job, unsigned long long *__restrict__ job_work) {
@@ -1416,9 +1726,10 @@ __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, do
 }
 
 inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
-                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const int32_t *tile_run, int axis) {
+                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const int32_t *tile_run, int axis,
+                       const float *q = nullptr) {
     return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
-                  (gi32p)tile_run, axis, 0};
+                  (gi32p)tile_run, (gq4p)q, axis, 0};
 }
 
 template <typename T>
@@ -1489,6 +1800,8 @@ struct yawhip_ctx {
     int band_grid_div = 4;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest;
                              // 1, 2, 4 and 8 measure the same at the headline)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
+    int band_fp32 = 1;       // band kernel on strip layouts of unit vectors: float32 classification + exact float64 for the
+                             // guard bands (k_count_band32); 0: every entry in float64 (k_count_band)
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
     int default_kernel = YAWHIP_KERNEL_AUTO;
     int lds_limit = 160 * 1024;
@@ -1497,6 +1810,7 @@ struct yawhip_ctx {
     View<int64_t> d_prefix;
     View<double> d_t;
     View<float> d_dthr;
+    View<float> d_thr32;
     View<double> d_rwin;
     DevBuf<Item> d_items;
     View<unsigned long long> d_ctr;
@@ -1523,6 +1837,7 @@ struct StripLayout {
     bool built = false;
     double *x = nullptr, *y = nullptr, *z = nullptr, *w = nullptr;
     int32_t *k = nullptr;             // bin id per object (patch-level layout of a binned catalogue)
+    float *q = nullptr;               // [n][4] float32 image {x, y, z, bin id bits} of every object (k_count_band32)
     int64_t *off = nullptr;           // [V+1] offsets of the runs
     std::vector<int64_t> h_off;       // same on the host
     std::vector<int64_t> h_vbase;     // [G+1] first run of every group
@@ -1535,11 +1850,11 @@ struct StripLayout {
     double obj_run = 0.0;             // run length seen by the typical object (sum len^2 / sum len)
     double same_bin = 0.0;            // fraction of neighbours in the layout's order that share their bin (binned patch-level layouts)
     void release() {
-        for (void *q : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)off, (void *)d_vbase, (void *)d_slo,
-                        (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_run[0], (void *)d_tile_run[1],
-                        (void *)d_tile_run[2]})
-            if (q) (void)hipFree(q);
-        x = y = z = w = nullptr; k = nullptr; off = d_vbase = d_slo = nullptr;
+        for (void *ptr : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)q, (void *)off, (void *)d_vbase, (void *)d_slo,
+                          (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_run[0], (void *)d_tile_run[1],
+                          (void *)d_tile_run[2]})
+            if (ptr) (void)hipFree(ptr);
+        x = y = z = w = nullptr; k = nullptr; q = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
         d_tile_run[0] = d_tile_run[1] = d_tile_run[2] = nullptr;
         built = false;
@@ -1676,6 +1991,17 @@ __global__ void k_gather_bins(int64_t n, const uint32_t *__restrict__ perm, cons
                               int n_bins, int32_t *__restrict__ bins) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) bins[i] = segment_of(off, (int)n_seg, (int64_t)perm[i]) % n_bins;
+}
+
+// float32 image of a strip layout: {x, y, z} rounded to nearest, the bin id (0 without bins) as the fourth word
+__global__ void k_make_q(int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                         const int32_t *__restrict__ bins, float *__restrict__ q) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f32x4 v;
+    v.x = (float)x[i]; v.y = (float)y[i]; v.z = (float)z[i];
+    v.w = __builtin_bit_cast(float, bins ? bins[i] : 0);
+    reinterpret_cast<f32x4 *>(q)[i] = v;
 }
 
 // How often two neighbours of the (strip, u)-sorted order share their redshift bin: ~1/B when redshift and position are
@@ -1877,11 +2203,13 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
     if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
     if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), n1 * sizeof(int32_t) + 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.q), n1 * 16 + 16);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
     if (e != hipSuccess) return bail(e, "strip layout");
     hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->x, c->y, c->z, c->w, L.x, L.y, L.z, L.w);
     if (want_bins)
         hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, c->nb, L.k);
+    hipLaunchKernelGGL(k_make_q, dim3(ngrid), dim3(256), 0, ctx->stream, n, L.x, L.y, L.z, want_bins ? L.k : nullptr, L.q);
     hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
                        L.off);
     std::vector<int64_t> voff((size_t)n_runs + 1);
@@ -1933,7 +2261,7 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     L.h_vbase = std::move(vbase);
     L.h_slo = std::move(slo);
     L.n_groups = n_groups;
-    L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) +
+    L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) + n * 16 +
                      (4 * (n_runs + 1) + 2 * (int64_t)n_groups + 1) * (int64_t)sizeof(int64_t);
     c->device_bytes += L.device_bytes;
     L.built = true;
@@ -2079,6 +2407,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
     if (!strcmp(key, "flush_stages_log2")) {
         if (value < 0 || value > 17) return fail(YAWHIP_ERR_INVALID, "flush_stages_log2 must be in [0, 17]");
         ctx->flush_log2 = (int)value;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "band_fp32")) {
+        ctx->band_fp32 = value != 0;
         return YAWHIP_OK;
     }
     if (!strcmp(key, "kernel")) {
@@ -2259,6 +2591,42 @@ struct CallState {
     int launches = 0, kernel = 0, mode = 0, n_orient = 0;
 };
 
+// Float32 bounds of every edge for k_count_band32 (see there): for unit vectors rounded to float32,
+//   |s32 - s| <= g(t) = 4.2e-7 sqrt(t) + 5e-7 t + 1e-12 near s = t,
+// so s32 < t - g proves s <= t and s32 > t + g proves s > t; in between the kernel evaluates in float64.
+//   n_edges == 2: {c, h_in, h_out, 0}: |s32 - c| < h_in proves t0 < s <= t1, |s32 - c| >= h_out proves the opposite
+//                 (both widths carry the rounding of the float32 subtraction);
+//   else per edge {t - g rounded down, t + g rounded up}.
+std::vector<float> build_thr32(const double *t, int n_bins, int n_edges) {
+    auto down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; };
+    auto up = [](double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; };
+    auto guard = [](double te) { return 4.2e-7 * std::sqrt(te) + 5e-7 * te + 1e-12; };
+    const int tw = thr32_width(n_edges);
+    std::vector<float> out((size_t)n_bins * tw, 0.f);
+    for (int k = 0; k < n_bins; ++k) {
+        const double *tk = t + (size_t)k * n_edges;
+        float *row = &out[(size_t)k * tw];
+        if (n_edges == 2) {
+            const double g0 = guard(tk[0]), g1 = guard(tk[1]);
+            const float c = (float)(0.5 * (tk[0] + tk[1]));
+            const double cd = (double)c;
+            const double h_in = std::min(cd - (tk[0] + g0), (tk[1] - g1) - cd) * (1.0 - 1e-6);
+            const double h_out = std::max(cd - (tk[0] - g0), (tk[1] + g1) - cd) * (1.0 + 1e-6);
+            row[0] = c;
+            row[1] = h_in > 0.0 ? down(h_in) : 0.f;   // |q| < 0 never holds: nothing is certain
+            row[2] = up(std::max(h_out, 0.0));
+            row[3] = 0.f;
+        } else {
+            for (int e = 0; e < n_edges; ++e) {
+                const double g = guard(tk[e]);
+                row[2 * e] = down(tk[e] - g);
+                row[2 * e + 1] = up(tk[e] + g);
+            }
+        }
+    }
+    return out;
+}
+
 // First half of yawhip_count_pairs on ONE device: everything up to and including the copy of the results into the
 // context's pinned buffer is put on the context's stream; nothing waits for the device (SWEEP's grid sizing aside).
 // job_work != nullptr: cost estimate only -- the item builder runs, evaluated pairs per job are returned, no counting.
@@ -2298,7 +2666,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     // the window search compares the sorted coordinate of both sides: the axes must agree
     if ((kernel == YAWHIP_KERNEL_SWEEP || kernel == YAWHIP_KERNEL_BAND) && c1->axis != c2->axis)
         kernel = unit ? YAWHIP_KERNEL_FILTER : YAWHIP_KERNEL_EXACT;
-    bool band = kernel == YAWHIP_KERNEL_BAND;  // exact FP64 on per-object bands: needs no unit vectors
+    // the band kernels park finished lanes on a sentinel at coordinate 4.0 and bound their searches by it: unit vectors only
+    if (kernel == YAWHIP_KERNEL_BAND && !unit) kernel = YAWHIP_KERNEL_EXACT;
+    bool band = kernel == YAWHIP_KERNEL_BAND;
     const bool sweep = kernel == YAWHIP_KERNEL_SWEEP || band;
     const bool filter = unit && kernel != YAWHIP_KERNEL_EXACT;
 
@@ -2377,6 +2747,15 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             L2[o] = mode == 3 ? &c2->seg[o] : &c2->strips[o];
         }
     }
+    // Float32 classification (k_count_band32) on strip layouts of unit vectors with up to four edges per bin. Where one
+    // side is binned (merged items) the roles are swapped against k_count_band: lane tiles come from the binned catalogue
+    // c1, the windows from the unbinned c2 (see the kernel).
+    const bool want32 = band && strip_items && unit && n_edges <= 4 && ctx->band_fp32 != 0 &&
+                        band32_lds(weighted_any, BCAP_MID, (merged ? n_bins : 1) * nf, merged && !uniform_t ? n_bins : 0, n_edges) <=
+                            (size_t)ctx->lds_limit;
+    bool swap = want32 && merged;
+    const yawhip_catalog *c_lane = swap ? c1 : c2, *c_strm = swap ? c2 : c1;
+    const StripLayout *const *LL = swap ? L1 : L2, *const *LS = swap ? L2 : L1;  // lane side, streamed side
     if (auto_pick && band && unit) {
         // The band kernel decides every entry of a per-object band in FP64: unbeatable while a band is a handful of
         // entries of which half are pairs (strip layouts of dense catalogues). Without strips a band is the whole
@@ -2387,13 +2766,18 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         if (!use_sweep) {
             double obj_run = 0.0;  // of the densest built orientation
             for (int o = 0; o < 3; ++o)
-                if (L1[o]) obj_run = std::max(obj_run, L1[o]->obj_run);
+                if (LS[o]) obj_run = std::max(obj_run, LS[o]->obj_run);
             use_sweep = obj_run < (double)BAND_MIN_STREAM_RUN;
         }
         if (use_sweep) {
             kernel = YAWHIP_KERNEL_SWEEP;
             band = false;
         }
+    }
+    const bool band32 = want32 && band;
+    if (!band32 && swap) {  // the sweep kernel streams c1 past lane tiles of c2
+        swap = false;
+        c_lane = c2; c_strm = c1; LL = L2; LS = L1;
     }
     int R = ctx->tile_r;
     double est_window = 0.0;  // band kernel: expected entries of one window
@@ -2402,8 +2786,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         if (strip_items) {  // lanes hold runs of a strip layout: their typical (mean) length decides
             int64_t n_runs = 1;
             for (int o = 0; o < 3; ++o)
-                if (L2[o]) n_runs = std::max(n_runs, L2[o]->h_vbase[(size_t)L2[o]->n_groups]);
-            max_seg = c2->n / std::max<int64_t>(n_runs, 1);
+                if (LL[o]) n_runs = std::max(n_runs, LL[o]->h_vbase[(size_t)LL[o]->n_groups]);
+            max_seg = c_lane->n / std::max<int64_t>(n_runs, 1);
             if (mode == 3) max_seg = std::max<int64_t>(max_seg, 4 * MWG * 2);  // at least two objects per lane: per-bin runs are
                                                                                 // sparse, the per-item cost outweighs the wider window
         } else {
@@ -2434,7 +2818,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 extent = n_ext ? extent / n_ext : 1.0;
                 return ((double)c->n / (double)runs) / std::max(extent, 1e-6);
             };
-            const double d1 = per_u(c1, L1), d2 = per_u(c2, L2);
+            const double d1 = per_u(c_strm, LS), d2 = per_u(c_lane, LL);
             est_window = 64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1;
         }
     }
@@ -2508,9 +2892,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         prefix.resize((size_t)n_sjobs + 1);
         job_runs.assign((size_t)3 * n_sjobs, 0);
         for (int64_t j = 0; j < n_sjobs; ++j) {
-            const int p = sjobs[(size_t)2 * j], q = sjobs[(size_t)2 * j + 1];
+            const int p = sjobs[(size_t)2 * j + (swap ? 1 : 0)], q = sjobs[(size_t)2 * j + (swap ? 0 : 1)];  // streamed, lane side
             const int o = orient[(size_t)(mode == 3 ? j / n_bins : j)];
-            const StripLayout &sl1 = *L1[o], &sl2 = *L2[o];
+            const StripLayout &sl1 = *LS[o], &sl2 = *LL[o];
             const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
             job_runs[(size_t)3 * j + 2] = o;
             prefix[(size_t)j] = n_items;
@@ -2585,9 +2969,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             if (!L1[o]) continue;
             const StripLayout &a = *L1[o], &b = *L2[o];
             h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx],
-                                 a.d_tile_run[tile_idx], o);
+                                 a.d_tile_run[tile_idx], o, a.q);
             h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx],
-                                     b.d_tile_run[tile_idx], o);
+                                     b.d_tile_run[tile_idx], o, b.q);
         }
     } else {
         h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, c1->axis);
@@ -2602,6 +2986,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const size_t o_t = take((size_t)n_bins * n_edges * sizeof(double));
     const size_t o_dthr = take((size_t)3 * n_bins * sizeof(float));
     const size_t o_rwin = take((size_t)n_bins * sizeof(double));
+    const std::vector<float> thr32 = band32 ? build_thr32(t, n_bins, n_edges) : std::vector<float>();
+    const size_t o_thr32 = take(thr32.size() * sizeof(float));
     const size_t o_tabs = take(sizeof h_tabs);
     HIP_TRY(ctx->in.reserve(off_in));
     if (strip_items) {
@@ -2614,6 +3000,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     memcpy(ctx->in.h + o_t, t, sizeof(double) * n_bins * n_edges);
     memcpy(ctx->in.h + o_dthr, dthr.data(), sizeof(float) * 3 * n_bins);
     memcpy(ctx->in.h + o_rwin, rwin.data(), sizeof(double) * n_bins);
+    if (!thr32.empty()) memcpy(ctx->in.h + o_thr32, thr32.data(), sizeof(float) * thr32.size());
     memcpy(ctx->in.h + o_tabs, h_tabs, sizeof h_tabs);
     HIP_TRY(hipMemcpyAsync(ctx->in.d, ctx->in.h, off_in, hipMemcpyHostToDevice, ctx->stream));
     ctx->d_jobs.ptr = reinterpret_cast<int32_t *>(ctx->in.d + o_jobs);
@@ -2621,6 +3008,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     ctx->d_t.ptr = reinterpret_cast<double *>(ctx->in.d + o_t);
     ctx->d_dthr.ptr = reinterpret_cast<float *>(ctx->in.d + o_dthr);
     ctx->d_rwin.ptr = reinterpret_cast<double *>(ctx->in.d + o_rwin);
+    ctx->d_thr32.ptr = reinterpret_cast<float *>(ctx->in.d + o_thr32);
     ctx->d_tabs.ptr = reinterpret_cast<DevTab *>(ctx->in.d + o_tabs);
     // results: [counters][counts][sums] in one device buffer, zeroed by one memset (sums are always fully written) and
     // fetched by one copy
@@ -2654,7 +3042,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         if (strip_items)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(bwg), 0, ctx->stream, ctx->d_tabs.ptr,
                                ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, ctx->d_prefix.ptr, (int)n_sjobs, reach,
-                               (int)tile, rwin_max, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
+                               (int)tile, rwin_max, swap ? 1 : 0, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
@@ -2735,7 +3123,46 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         int flush_log2 = ctx->flush_log2;
         while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) > (1ull << 32)) --flush_log2;
         const unsigned flush_mask = (1u << flush_log2) - 1u;
-        auto launch_band = [&](bool wgt) -> hipError_t {
+        const size_t lds_band32 = band32_lds(weighted_any, cap, lean_bins * nf, merged && !uniform_t ? n_bins : 0, n_edges);
+        auto launch_band32 = [&](bool wgt) -> hipError_t {
+#define YAW_LAUNCH_B32(RR, CC, WW, NN, MM, UU)                                                                        \
+    do {                                                                                                              \
+        auto kern = k_count_band32<RR, CC, WW, NN, MM, UU>;                                                           \
+        if (lds_band32 > 64 * 1024) {                                                                                 \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_band32);         \
+            if (ea != hipSuccess) return ea;                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band32, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
+                           n_bins, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, ctx->d_counts.ptr,    \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
+    } while (0)
+#define YAW_LAUNCH_B32_R(WW, NN, MM, UU)                                                                              \
+    do {                                                                                                              \
+        if (R == 1) YAW_LAUNCH_B32(1, BCAP, WW, NN, MM, UU);                                                          \
+        else if (R == 2 && cap == BCAP) YAW_LAUNCH_B32(2, BCAP, WW, NN, MM, UU);                                      \
+        else if (R == 2) YAW_LAUNCH_B32(2, BCAP_MID, WW, NN, MM, UU);                                                 \
+        else YAW_LAUNCH_B32(4, BCAP_MID, WW, NN, MM, UU);                                                             \
+    } while (0)
+#define YAW_LAUNCH_B32_M(WW, NN)                                                                                      \
+    do {                                                                                                              \
+        if (!merged) YAW_LAUNCH_B32_R(WW, NN, false, true);                                                           \
+        else if (uniform_t) YAW_LAUNCH_B32_R(WW, NN, true, true);                                                     \
+        else YAW_LAUNCH_B32_R(WW, NN, true, false);                                                                   \
+    } while (0)
+#define YAW_LAUNCH_B32_N(WW)                                                                                          \
+    do {                                                                                                              \
+        if (n_edges == 2) YAW_LAUNCH_B32_M(WW, 2); else if (n_edges == 3) YAW_LAUNCH_B32_M(WW, 3);                    \
+        else YAW_LAUNCH_B32_M(WW, 4);                                                                                 \
+    } while (0)
+            if (wgt) YAW_LAUNCH_B32_N(true); else YAW_LAUNCH_B32_N(false);
+#undef YAW_LAUNCH_B32_N
+#undef YAW_LAUNCH_B32_M
+#undef YAW_LAUNCH_B32_R
+#undef YAW_LAUNCH_B32
+            return hipGetLastError();
+        };
+        auto launch_band64 = [&](bool wgt) -> hipError_t {
 #define YAW_LAUNCH_BAND(RR, CC, WW, NN, MM, UU)                                                                       \
     do {                                                                                                              \
         auto kern = k_count_band<RR, CC, WW, NN, MM, UU>;                                                             \
@@ -2773,6 +3200,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
 #undef YAW_LAUNCH_BAND
             return hipGetLastError();
         };
+        auto launch_band = [&](bool wgt) -> hipError_t { return band32 ? launch_band32(wgt) : launch_band64(wgt); };
         if (run_unweighted) {
             HIP_TRY(launch_band(false));
             ++launches;
