@@ -12,7 +12,8 @@ from dataclasses import dataclass
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libyawhip.so")
+# YAW_AMD_LIB points experiments at a variant build (tools/build_variant.py); the product loads the in-tree library
+LIB_PATH = os.environ.get("YAW_AMD_LIB") or os.path.join(_PKG_DIR, "libyawhip.so")
 
 DEFAULT_STRIP_MICRO = 5000  # the library's default strip grid spacing, in 1e-6 chord units
 KERNEL_AUTO, KERNEL_EXACT, KERNEL_FILTER, KERNEL_SWEEP, KERNEL_BAND = 0, 1, 2, 3, 4

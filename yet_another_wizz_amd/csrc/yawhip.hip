@@ -140,16 +140,22 @@ __host__ __device__ inline int item_orient(const Item &it) { return (int)((unsig
 typedef const __attribute__((address_space(1))) double *gf64p;
 typedef const __attribute__((address_space(1))) int32_t *gi32p;
 typedef const __attribute__((address_space(1))) int64_t *gi64p;
+#ifndef YAW_B32_PREFETCH
+#define YAW_B32_PREFETCH 0  // next trip's LDS reads issued before this trip's arithmetic: 0.404 against 0.379 ms (registers -> 5 waves)
+#endif
+#ifndef YAW_B32_WAVES
+#define YAW_B32_WAVES 1  // > 1: waves per SIMD every variant is compiled for (experiments). Default: 7 for the plain count (72 VGPRs
+#endif                   // instead of 79: 0.359 against 0.371 ms at the headline; 8 spills: 0.405), the compiler's choice elsewhere
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) f32x4 *gq4p;
+typedef const __attribute__((address_space(1))) float *gf32p;
 struct DevTab {
     gf64p x, y, z, w;          // columns; w may be null
     gi32p k;                   // bin id per object (merged cross-correlation layouts), else null
     gi64p off;                 // run offsets [V+1] (strip layouts) or segment offsets
     gi64p vbase, slo, tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
     gi32p tile_run;            // strip layouts: run of every lane tile
-    gq4p q;                    // strip layouts: float32 image {x, y, z, bin id} of every object (k_count_band32)
+    gf32p qx, qy, qz;          // strip layouts: float32 images of the columns (k_count_band32)
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
@@ -1395,12 +1401,22 @@ constexpr float PAD_COORD32 = 4.0f;
 __host__ __device__ constexpr int thr32_width(int ne) { return ne == 2 ? 4 : 2 * ne; }
 // dynamic LDS of a k_count_band32 workgroup (host and device agree through this one function)
 __host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots, int thr_rows, int ne) {
-    return (size_t)(cap + 1) * 16 + (weighted ? (size_t)(cap + 2) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) +
+    return (size_t)3 * (cap + 4) * 4 + (weighted ? (size_t)(cap + 2) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) +
            (size_t)thr_rows * thr32_width(ne) * 4 + 32;
 }
 
+// The exact predicate of the parity contract on the float64 columns, for an evaluation the float32 classes left undecided
+// (rare: kept out of line so that its addresses and temporaries do not live in the walk loop's registers).
+__device__ __attribute__((noinline)) double band32_exact_s(gf64p lx, gf64p ly, gf64p lz, int64_t li, gf64p sx, gf64p sy, gf64p sz,
+                                                           int64_t gi) {
+    const double dx = lx[li] - sx[gi], dy = ly[li] - sy[gi], dz = lz[li] - sz[gi];
+    const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const double sxy = xx + yy;
+    return sxy + zz;
+}
+
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED && NE == 2 && UNI ? 7 : 1))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                      const double *__restrict__ t, const float *__restrict__ thr32,
                                                      const double *__restrict__ rwin_k, unsigned flush_mask,
                                                      unsigned long long *__restrict__ out_counts,
@@ -1416,7 +1432,8 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
     const int nkb = MERGED ? n_bins : 1;
     const int nslots = nkb * NF;
     unsigned char *p = lds_dyn;
-    f32x4 *stage = reinterpret_cast<f32x4 *>(p); p += (size_t)(CAP + 1) * 16;
+    constexpr unsigned COLB = (CAP + 4) * 4;  // bytes of one staged float32 column: CAP entries, the sentinel, the tail of a 16-byte DMA
+    float *stage = reinterpret_cast<float *>(p); p += (size_t)3 * COLB;  // columns x, y, z
     double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 2) * 8;
     HistT *hist = reinterpret_cast<HistT *>(p); p += (size_t)nslots * sizeof(HistT);
     p = reinterpret_cast<unsigned char *>(((size_t)p + 15) & ~(size_t)15);
@@ -1446,11 +1463,17 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
 
         __syncthreads();  // the previous item of this workgroup has left the LDS
         auto stage_in = [&](int64_t first, int n) {
-            const gq4p gq = cs.q + b0 + first;
+            // four entries of one column per lane and instruction (16 bytes; the last lane may run up to three entries past
+            // the window: into the next run, and into the column's slack in LDS)
+            const gf32p gx = cs.qx + b0 + first, gy = cs.qy + b0 + first, gz = cs.qz + b0 + first;
 #pragma unroll
-            for (int c = 0; c < (CAP + 63) / 64; ++c) {
-                const unsigned e = (unsigned)(c * 64 + lane);
-                if (e < (unsigned)n) __builtin_amdgcn_global_load_lds(gq + e, lds_ptr(a_stage + c * 1024), 16, 0, 0);
+            for (int c = 0; c < (CAP + 255) / 256; ++c) {
+                const unsigned e = (unsigned)(c * 256 + 4 * lane);
+                if (e < (unsigned)n) {
+                    __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_stage + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_stage + COLB + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_stage + 2 * COLB + c * 1024), 16, 0, 0);
+                }
             }
             if (WEIGHTED && cs.w) {
 #pragma unroll
@@ -1472,10 +1495,10 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
         for (int r = 0; r < R; ++r) {
             const bool have = r < n_own;
             const unsigned ic = have ? (unsigned)(lane * R + r) : 0u;
-            const f32x4 q = (cl.q + it.a0)[ic];
-            ax[r] = have ? q.x : PAD_COORD32; ay[r] = have ? q.y : PAD_COORD32; az[r] = have ? q.z : PAD_COORD32;
-            const float qw = q.w;  // (a bit cast of the vector element itself read element 0)
-            kb[r] = MERGED ? (have ? __float_as_int(qw) : 0) : 0;
+            ax[r] = have ? (cl.qx + it.a0)[ic] : PAD_COORD32;
+            ay[r] = have ? (cl.qy + it.a0)[ic] : PAD_COORD32;
+            az[r] = have ? (cl.qz + it.a0)[ic] : PAD_COORD32;
+            kb[r] = MERGED ? (have ? (cl.k + it.a0)[ic] : 0) : 0;
             aw[r] = (WEIGHTED && cl.w) ? (have ? (cl.w + it.a0)[ic] : 0.0) : (have ? 1.0 : 0.0);
         }
         // thresholds: per lane object (its bin's row from the LDS table) or one row for the wave
@@ -1558,7 +1581,7 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
             }
             __syncthreads();  // the stage has landed (the compiler drains the LDS-DMA in front of the barrier)
             if (lane == 0) {  // sentinel behind the stage: beyond every edge of every lane object
-                stage[n] = f32x4{PAD_COORD32, PAD_COORD32, PAD_COORD32, 0.f};
+                stage[n] = PAD_COORD32; stage[COLB / 4 + n] = PAD_COORD32; stage[2 * (COLB / 4) + n] = PAD_COORD32;
                 if (WEIGHTED) sw[n] = 0.0;
             }
             if (WEIGHTED && !cs.w)
@@ -1567,29 +1590,67 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
             // band of the lane inside this stage: [lo, hi) = entries with klo <= key <= khi, by two branch-free binary
             // searches on LDS byte addresses (q = address of entry lo - 1; a probe beyond the stage is clamped onto the
             // sentinel, whose key 4.0 fails both comparisons)
-            const unsigned a_key = a_stage + 4u * (unsigned)cl.axis;
-            const unsigned a_sent = a_key + ((unsigned)n << 4);
-            unsigned ql = a_key - 16u, qh = ql;
-            for (unsigned step = 16u << (31 - __builtin_clz(n)); step >= 16u; step >>= 1) {  // largest power of two <= n
+            const unsigned a_key = a_stage + COLB * (unsigned)cl.axis;
+            const unsigned a_sent = a_key + ((unsigned)n << 2);
+            unsigned ql = a_key - 4u, qh = ql;
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
+            for (unsigned step = 0; step >= 4u; step >>= 1) {  // diagnostics: no search either
+#else
+            for (unsigned step = 4u << (31 - __builtin_clz(n)); step >= 4u; step >>= 1) {  // largest power of two <= n
+#endif
                 const unsigned pl = ql + step, ph = qh + step;
                 const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent ? pl : a_sent);
                 const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent ? ph : a_sent);
                 ql = kl < klo ? pl : ql;    // entries [0, lo) have key <  klo
                 qh = kh <= khi ? ph : qh;   // entries [0, hi) have key <= khi
             }
-            int lo = (int)((ql + 16u - a_key) >> 4), hi = (int)((qh + 16u - a_key) >> 4);
+            int lo = (int)((ql + 4u - a_key) >> 2), hi = (int)((qh + 4u - a_key) >> 2);
             if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
             const int len = hi - lo;
             nev += (unsigned int)(len * n_own);
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1
+            const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
+#else
             const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
+#endif
 
-            unsigned cur = a_stage + ((unsigned)lo << 4);
-            const unsigned last = a_stage + ((unsigned)n << 4);
+            unsigned cur = a_stage + ((unsigned)lo << 2);
+            const unsigned last = a_stage + ((unsigned)n << 2);
+            // One entry per trip: three 4-byte reads from columns a fixed distance apart (lanes read nearly consecutive words
+            // of a column). The reads of the NEXT trip are issued before this trip's arithmetic (YAW_B32_PREFETCH).
+            struct Entry { float x, y, z; double w; unsigned a; };
+            auto read_entry = [&](unsigned at) {
+                Entry e;
+                e.a = at < last ? at : last;
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -1
+                e.x = klo; e.y = khi; e.z = klo;  // diagnostics: the walk's arithmetic without its LDS reads (wrong counts)
+                asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z));
+#else
+                e.x = *(const __attribute__((address_space(3))) float *)(size_t)e.a;
+                e.y = *(const __attribute__((address_space(3))) float *)(size_t)(e.a + COLB);
+                e.z = *(const __attribute__((address_space(3))) float *)(size_t)(e.a + 2 * COLB);
+#endif
+                e.w = WEIGHTED ? lds_f64(((e.a - a_stage) << 1) + a_sw) : 1.0;
+                return e;
+            };
+#if YAW_B32_PREFETCH
+            Entry nxt = read_entry(cur);
+            cur += 4;
+#endif
             for (int s = 0; s < steps; ++s) {
-                const unsigned a16 = cur < last ? cur : last;
-                cur += 16;
-                const f32x4 en = *(const __attribute__((address_space(3))) f32x4 *)(size_t)a16;
-                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) >> 1) + a_sw) : 1.0;
+#if YAW_B32_PREFETCH
+                const Entry en = nxt;
+                nxt = read_entry(cur);  // (one read past the last trip: clamped onto the sentinel)
+#else
+                const Entry en = read_entry(cur);
+#endif
+                cur += 4;
+                const unsigned a16 = en.a;
+                const double ew = en.w;
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -2
+                cnt[0][0] += __float_as_uint(en.x) ^ __float_as_uint(en.y) ^ __float_as_uint(en.z);  // diagnostics: the LDS reads alone
+                continue;
+#endif
                 float s32[R];
                 if constexpr (R >= 2) {
 #pragma unroll
@@ -1628,15 +1689,11 @@ __global__ __launch_bounds__(64) void k_count_band32(const DevTab *__restrict__ 
                 }
                 if (any_mask != 0ull) {
                     // inside a guard band: the exact float64 predicate on the float64 columns decides (rare)
-                    const unsigned eidx = (a16 - a_stage) >> 4;
+                    const unsigned eidx = (a16 - a_stage) >> 2;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const int64_t gi = b0 + st0 + eidx, li = it.a0 + lane * R + r;
-                            const double dx = cl.x[li] - cs.x[gi], dy = cl.y[li] - cs.y[gi], dz = cl.z[li] - cs.z[gi];
-                            const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                            const double sxy = xx + yy;
-                            const double sd = sxy + zz;
+                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx);
                             const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
                             if constexpr (NE == 2) {
                                 const bool in = sd > tk[0] && sd <= tk[1];
@@ -1727,9 +1784,9 @@ __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, do
 
 inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
                        const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const int32_t *tile_run, int axis,
-                       const float *q = nullptr) {
+                       const float *q = nullptr, int64_t q_stride = 0) {
     return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
-                  (gi32p)tile_run, (gq4p)q, axis, 0};
+                  (gi32p)tile_run, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), axis, 0};
 }
 
 template <typename T>
@@ -1837,7 +1894,8 @@ struct StripLayout {
     bool built = false;
     double *x = nullptr, *y = nullptr, *z = nullptr, *w = nullptr;
     int32_t *k = nullptr;             // bin id per object (patch-level layout of a binned catalogue)
-    float *q = nullptr;               // [n][4] float32 image {x, y, z, bin id bits} of every object (k_count_band32)
+    float *q = nullptr;               // [3][q_stride] float32 images of x, y, z (k_count_band32)
+    int64_t q_stride = 0;
     int64_t *off = nullptr;           // [V+1] offsets of the runs
     std::vector<int64_t> h_off;       // same on the host
     std::vector<int64_t> h_vbase;     // [G+1] first run of every group
@@ -1993,15 +2051,14 @@ __global__ void k_gather_bins(int64_t n, const uint32_t *__restrict__ perm, cons
     if (i < n) bins[i] = segment_of(off, (int)n_seg, (int64_t)perm[i]) % n_bins;
 }
 
-// float32 image of a strip layout: {x, y, z} rounded to nearest, the bin id (0 without bins) as the fourth word
+// float32 images of a strip layout's columns, rounded to nearest: [3][stride]
 __global__ void k_make_q(int64_t n, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
-                         const int32_t *__restrict__ bins, float *__restrict__ q) {
+                         int64_t stride, float *__restrict__ q) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    f32x4 v;
-    v.x = (float)x[i]; v.y = (float)y[i]; v.z = (float)z[i];
-    v.w = __builtin_bit_cast(float, bins ? bins[i] : 0);
-    reinterpret_cast<f32x4 *>(q)[i] = v;
+    q[i] = (float)x[i];
+    q[stride + i] = (float)y[i];
+    q[2 * stride + i] = (float)z[i];
 }
 
 // How often two neighbours of the (strip, u)-sorted order share their redshift bin: ~1/B when redshift and position are
@@ -2203,13 +2260,14 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.z), col);
     if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w), col);
     if (e == hipSuccess && want_bins) e = hipMalloc(reinterpret_cast<void **>(&L.k), n1 * sizeof(int32_t) + 16);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.q), n1 * 16 + 16);
+    L.q_stride = (int64_t)((n1 + 3) & ~(size_t)3) + 8;  // a 16-byte load of the band kernel may run up to 12 bytes past a column
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.q), (size_t)3 * L.q_stride * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
     if (e != hipSuccess) return bail(e, "strip layout");
     hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->x, c->y, c->z, c->w, L.x, L.y, L.z, L.w);
     if (want_bins)
         hipLaunchKernelGGL(k_gather_bins, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->off, nseg, c->nb, L.k);
-    hipLaunchKernelGGL(k_make_q, dim3(ngrid), dim3(256), 0, ctx->stream, n, L.x, L.y, L.z, want_bins ? L.k : nullptr, L.q);
+    hipLaunchKernelGGL(k_make_q, dim3(ngrid), dim3(256), 0, ctx->stream, n, L.x, L.y, L.z, L.q_stride, L.q);
     hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
                        L.off);
     std::vector<int64_t> voff((size_t)n_runs + 1);
@@ -2261,7 +2319,7 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     L.h_vbase = std::move(vbase);
     L.h_slo = std::move(slo);
     L.n_groups = n_groups;
-    L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) + n * 16 +
+    L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) + 3 * L.q_stride * (int64_t)sizeof(float) +
                      (4 * (n_runs + 1) + 2 * (int64_t)n_groups + 1) * (int64_t)sizeof(int64_t);
     c->device_bytes += L.device_bytes;
     L.built = true;
@@ -2969,9 +3027,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             if (!L1[o]) continue;
             const StripLayout &a = *L1[o], &b = *L2[o];
             h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx],
-                                 a.d_tile_run[tile_idx], o, a.q);
+                                 a.d_tile_run[tile_idx], o, a.q, a.q_stride);
             h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx],
-                                     b.d_tile_run[tile_idx], o, b.q);
+                                     b.d_tile_run[tile_idx], o, b.q, b.q_stride);
         }
     } else {
         h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, c1->axis);
