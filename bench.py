@@ -318,24 +318,54 @@ def main():
         count_ms = count_ms_sum / max(args.steps, 1) if count_ms_sum > 0 else kernel_ms / max(args.steps, 1)
         k_s = max(count_ms, 1e-9) / 1e3
         kernel_name = {1: "exact", 2: "filter", 3: "sweep", 4: "band"}.get(stats.kernel_used, str(stats.kernel_used))
-        # HBM traffic of the count kernel is not measurable from inside this process (rocprofv3 --pmc passes); it is
-        # quoted from the committed PMC run of the SAME configuration and kernel, with its provenance, or left null
-        traffic, traffic_source = None, None
+        # HBM traffic and SQ counters of the count kernel are not measurable from inside this process (rocprofv3 --pmc
+        # passes); they are quoted from the committed PMC run of the SAME configuration and kernel -- and only while the
+        # kernel sources still hash to what that run was made with (build.source_sha16), else null
+        from yet_another_wizz_amd.build import source_sha16
+
+        traffic, traffic_source, sq_valu = None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 entry = json.load(f).get(traffic_key(args, kernel_name))
             if isinstance(entry, dict):
-                traffic = entry.get("bytes")
-                traffic_source = {k: entry.get(k) for k in ("source", "commit", "date", "method")}
+                fresh = entry.get("source_sha16") == source_sha16()
+                traffic_source = {k: entry.get(k) for k in ("source", "commit", "date", "method", "source_sha16")}
+                traffic_source["matches_current_sources"] = fresh
+                if fresh:
+                    traffic = entry.get("bytes")
+                    sq_valu = entry.get("sq_insts_valu")
         fp64_equiv = stats.candidate_pairs * 8.0 / k_s / 1e12
         hbm_gbps = stats.algorithmic_bytes / k_s / 1e9
         fp32_tflops = stats.evaluated_pairs * 5.0 / k_s / 1e12
+        peak_nofma = FP64_VECTOR_PEAK_TFLOPS / 2.0
         if stats.kernel_used == 1:
             roofline = dict(
-                bound="valu_fp64", achieved=fp64_equiv, peak=FP64_VECTOR_PEAK_TFLOPS / 2.0, unit="TFLOP/s",
-                frac=fp64_equiv / (FP64_VECTOR_PEAK_TFLOPS / 2.0), traffic=traffic, traffic_source=traffic_source,
+                bound="valu_fp64", achieved=fp64_equiv, peak=peak_nofma, unit="TFLOP/s",
+                frac=fp64_equiv / peak_nofma, traffic=traffic, traffic_source=traffic_source,
                 note="FP64 vector ALU, no FMA allowed by the parity contract: 8 flop per candidate pair",
+            )
+        elif stats.kernel_used == 4:
+            # BAND: what binds the kernel is vector-ALU issue, not HBM. The roofline is
+            # the parity contract's predicate -- 8 non-FMA FP64 flop -- over the entries the kernel really EVALUATES, against
+            # half the FP64 vector peak. (The kernel decides an entry in float32 wherever float32 can and in float64 inside the
+            # guard bands, so this is an FP64-EQUIVALENT rate: it can exceed what FP64 arithmetic could reach.)
+            ev_tflops = stats.evaluated_pairs * 8.0 / k_s / 1e12
+            roofline = dict(
+                bound="valu_fp64", achieved=ev_tflops, peak=peak_nofma, unit="TFLOP/s", frac=ev_tflops / peak_nofma,
+                traffic=traffic, traffic_source=traffic_source,
+                achieved_hbm_gbps=(traffic / k_s / 1e9 if traffic else None),
+                achieved_hbm_frac=(traffic / k_s / 1e9 / HBM_PEAK_GBPS if traffic else None),
+                evaluated_entries_per_launch=stats.evaluated_pairs,
+                essential_valu_frac=(stats.evaluated_pairs * 10.0 / 64.0 / sq_valu if sq_valu else None),
+                note="achieved = evaluated band entries x 8 FP64-equivalent flop / count-kernel time, peak = FP64 vector peak "
+                     "without FMA; achieved_hbm_gbps = HBM bytes of the count kernel from the rocprofv3 PMC run named in "
+                     "traffic_source ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes) / count-kernel time -- the "
+                     "figure BASELINE.json's metric names; essential_valu_frac = evaluated entries x 10 lane operations "
+                     "(8 flop + 2 compares) / 64 lanes over the wave-level VALU instructions the SQ counted; all three null "
+                     "when the committed counters were taken with other kernel sources",
+                brute_force_equivalent=dict(achieved_tflops=fp64_equiv, peak_tflops=peak_nofma, frac=fp64_equiv / peak_nofma,
+                                            note="candidate pairs x 8 FP64 flop / time; > 1 because culled pairs are never evaluated"),
             )
         else:
             roofline = dict(
@@ -344,18 +374,12 @@ def main():
                 note="algorithmic bytes = per linked patch pair, every object of both patches once (24 B, 32 B "
                      "weighted); traffic = HBM bytes per launch from the rocprofv3 PMC run named in traffic_source "
                      "((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes), null if none is committed for this "
-                     "configuration",
-                evaluated=(dict(entries_per_launch=stats.evaluated_pairs, flop_per_entry=8,
-                                achieved_tflops=stats.evaluated_pairs * 8.0 / k_s / 1e12,
-                                peak_tflops=FP64_VECTOR_PEAK_TFLOPS / 2.0,
-                                frac=stats.evaluated_pairs * 8.0 / k_s / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
-                                note="band kernel: every entry of a per-object band is decided by the exact FP64 predicate")
-                           if stats.kernel_used == 4 else
-                           dict(evaluated_pairs_per_launch=stats.evaluated_pairs, flop_per_pair=5,
-                                achieved_tflops=fp32_tflops, peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
-                                frac=fp32_tflops / FP32_VECTOR_PEAK_TFLOPS, note="FP32 pre-filter of the sweep / filter paths")),
-                brute_force_equivalent=dict(achieved_tflops=fp64_equiv, peak_tflops=FP64_VECTOR_PEAK_TFLOPS / 2.0,
-                                            frac=fp64_equiv / (FP64_VECTOR_PEAK_TFLOPS / 2.0),
+                     "configuration and these kernel sources",
+                evaluated=dict(evaluated_pairs_per_launch=stats.evaluated_pairs, flop_per_pair=5,
+                               achieved_tflops=fp32_tflops, peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
+                               frac=fp32_tflops / FP32_VECTOR_PEAK_TFLOPS, note="FP32 pre-filter of the sweep / filter paths"),
+                brute_force_equivalent=dict(achieved_tflops=fp64_equiv, peak_tflops=peak_nofma,
+                                            frac=fp64_equiv / peak_nofma,
                                             note="candidate pairs x 8 FP64 flop / time; > 1 because culled pairs "
                                                  "are never evaluated"),
             )
@@ -364,7 +388,10 @@ def main():
             launch_ms=count_ms, all_kernels_ms=stats.kernel_ms,
             fixed_cost_ms=elapsed / max(args.steps, 1) * 1e3 - count_ms,  # everything of a step that is not the count kernel
             culled_fraction=1.0 - stats.evaluated_pairs / max(stats.candidate_pairs, 1),
-            hbm_algorithmic_gbps=hbm_gbps, hbm_peak_gbps=HBM_PEAK_GBPS, hbm_frac=hbm_gbps / HBM_PEAK_GBPS,
+            hbm_algorithmic_gbps=hbm_gbps, hbm_peak_gbps=HBM_PEAK_GBPS, hbm_algorithmic_frac=hbm_gbps / HBM_PEAK_GBPS,
+            hbm_algorithmic_note="SECONDARY figure: SURVEY.md 8(d)'s algorithmic bytes (every object of both patches once per "
+                                 "linked patch pair) / count-kernel time. Re-reads of a patch are served by L2 / MALL, so this "
+                                 "is not HBM utilisation (achieved_hbm_gbps is)",
         )
         base = None
         if world == 1 and args.cpu_seconds > 0:

@@ -2,8 +2,12 @@
 
 ``tests/golden/fullsize_reference_totals.json`` holds, per scale and redshift bin, the pair totals the reference's own
 ``PatchLinkage.count_pairs`` produced for exactly these inputs (``tools/time_reference.py``, build container; the inputs
-are ``bench.py``'s recipe with fixed seeds, so they are regenerated here bit for bit). On top of that: the oracle on a
-few whole jobs, the other device code paths on samples of jobs, symmetry and run-to-run reproducibility.
+are ``bench.py``'s recipe with fixed seeds, so they are regenerated here bit for bit), and
+``tests/golden/fullsize_slots_*.npz`` the reference's values SLOT BY SLOT -- ``counts[scale][:, i, j]`` of every linked
+patch pair (config #3, unweighted and weighted) or of every eighth one (configs #4, #5) plus its ``sum_weights`` -- so
+a job that landed in the wrong ``[i, j]`` slot cannot hide in a total (src/yaw/correlation/measurements.py:354-364).
+On top of that: the oracle on a few whole jobs, the other device code paths on samples of jobs, symmetry and run-to-run
+reproducibility.
 
   config #3  10M x 10M, 30 z-bins, 64 patches, DD of a cross-correlation (unweighted: totals must match exactly)
   config #4  10M data + 100M randoms, per-object weights, 64 patches, autocorrelation DD / DR / RR (1e-10 relative)
@@ -26,6 +30,30 @@ pytestmark = pytest.mark.gpu
 def golden():
     with open(os.path.join(GOLDEN, "fullsize_reference_totals.json")) as f:
         return json.load(f)
+
+
+def _slots(name):
+    return np.load(os.path.join(GOLDEN, f"fullsize_slots_{name}.npz"))
+
+
+def _check_slots(result, slots, name, exact):
+    """result: list of NormalisedCounts per scale, as ``PatchLinkage.count_pairs`` returns them; slots: the reference's
+    ``counts[s][:, i, j]`` for the patch pairs ``<name>_ids`` and its ``sum_weights``."""
+    ids, values = slots[f"{name}_ids"], slots[f"{name}_values"]  # [n, 2], [n, S, B]
+    assert values.shape[1] == len(result)
+    for s, res in enumerate(result):
+        got = res.counts.counts[:, ids[:, 0], ids[:, 1]].T  # [n, B]
+        if exact:
+            assert np.array_equal(got, values[:, s]), f"{name} scale {s}"
+        else:
+            np.testing.assert_allclose(got, values[:, s], rtol=1e-10, atol=0, err_msg=f"{name} scale {s}")
+    assert values.sum() > 0
+    sw = result[0].sum_weights
+    for got, key in ((sw.sum_weights1, "sum_weights1"), (sw.sum_weights2, "sum_weights2")):
+        if exact:
+            assert np.array_equal(got, slots[f"{name}_{key}"]), key
+        else:  # summation order of the weights differs from the reference's (SURVEY.md section 7)
+            np.testing.assert_allclose(got, slots[f"{name}_{key}"], rtol=1e-12, atol=0, err_msg=key)
 
 
 def _as_cat(layout):
@@ -65,9 +93,20 @@ def test_config3_headline_totals_match_reference(golden):
     assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == 1 and st.n_orientations == 3
     assert st.candidate_pairs == g["candidate_pairs"]
     assert np.array_equal(_per_scale_bin(combine, fine, jobs, False), np.array(g["pairs_per_scale_bin"]["DD"]))
-    # the public entry point scatters the same numbers
-    (counts,) = links.count_pairs(ref, unk)
+    # the public entry point scatters the same numbers -- and every one of the 440 x 30 slots holds the reference's value
+    result = links.count_pairs(ref, unk)
+    (counts,) = result
     assert np.array_equal(counts.counts.counts.sum(axis=(1, 2)), np.array(g["pairs_per_scale_bin"]["DD"][0]))
+    slots = _slots("config3")
+    assert slots["DD_ids"].shape == (440, 2) and slots["candidate_pairs"] == st.candidate_pairs
+    _check_slots(result, slots, "DD", exact=True)
+    assert np.count_nonzero(counts.counts.counts.sum(axis=0)) <= 440  # nothing outside the linked pairs
+    # the float64 band kernel (band_fp32 = 0) on every 10th job: the same counts
+    ctx = engine.get_context()
+    ctx.set_option("band_fp32", 0)
+    f64, st64 = engine.count_fine(lref, lunk, jobs[::10], t)
+    ctx.set_option("band_fp32", 1)
+    assert st64.kernel_used == _lib.KERNEL_BAND and np.array_equal(f64, fine[::10])
     # the other device paths on every 40th job, the oracle on one whole job (2.4e10 candidate pairs)
     sample = jobs[::40]
     for kernel in ("sweep", "filter"):
@@ -99,6 +138,7 @@ def test_config5_three_scales_128_patches(golden):
     assert totals.shape == (3, 30) and np.array_equal(totals, np.array(g["pairs_per_scale_bin"]["DD"]))
     again, _ = engine.count_fine(lref, lunk, jobs, t)
     assert np.array_equal(again, fine)
+    _check_slots(links.count_pairs(ref, unk), _slots("config5"), "DD", exact=True)  # every 8th linked pair, 3 scales x 30 bins
     sample = jobs[::60]
     f2, _ = engine.count_fine(lref, lunk, sample, t, kernel="sweep")
     assert np.array_equal(f2, fine[::60])
@@ -154,6 +194,10 @@ def test_config4_weighted_autocorrelation_with_10x_randoms(golden):
     # the public entry point end to end (catalogues resident): Landy-Szalay amplitudes are finite and small
     (cf,) = yaw.autocorrelate(config, data, rand)
     assert cf.dd is not None and cf.dr is not None and cf.rr is not None
+    # slot by slot against the reference (every 8th job of DD, DR, RR; the diagonal jobs carry the reference's x 0.5)
+    slots = _slots("config4")
+    for name, res in (("DD", cf.dd), ("DR", cf.dr), ("RR", cf.rr)):
+        _check_slots([res], slots, name, exact=False)
     w = cf.sample().data
     assert np.all(np.isfinite(w)) and np.all(np.abs(w) < 0.05)  # uniform sky: no clustering
     data.drop_layouts()

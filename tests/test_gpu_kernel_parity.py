@@ -225,6 +225,58 @@ def test_non_unit_vectors_fall_back_to_exact(ctx):
     assert stats.kernel_used == _lib.KERNEL_EXACT
 
 
+@pytest.mark.parametrize("kernel", ["auto", "band", "sweep"])
+def test_non_unit_vectors_beyond_the_band_sentinel(ctx, kernel):
+    """The band kernels park finished lanes on a sentinel at coordinate 4.0 and bound their searches by it: input that
+    is not made of unit vectors -- here coordinates around 6, beyond the sentinel -- must never reach them: they are
+    counted by the exact FP64 brute-force kernel, counts equal the oracle's."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(12)
+    centre = np.array([6.0, 5.0, 4.5])
+    a = rng.normal(size=(900, 3)) * 0.02 + centre
+    b = rng.normal(size=(1100, 3)) * 0.02 + centre
+    c1, c2 = _single(a, None), _single(b, None)
+    t = np.array([[1e-5, 2e-4, 1e-3]])
+    exp, _ = oracle.count_jobs(c1, c2, [[0, 0]], t)
+    counts, _, stats = _lib.count_pairs(ctx, _upload(ctx, c1), _upload(ctx, c2), [[0, 0]], t, kernel=kernel)
+    assert np.array_equal(counts, exp) and exp.sum() > 1000
+    # (a sweep request keeps its windowed items, evaluated by the exact FP64 kernel: no sentinel involved)
+    assert stats.kernel_used == (_lib.KERNEL_SWEEP if kernel == "sweep" else _lib.KERNEL_EXACT)
+
+
+@pytest.mark.parametrize("fp32", [0, 1])
+def test_band_kernel_float64_and_float32_classification_agree(ctx, fp32):
+    """``band_fp32`` selects between the band kernel that decides every entry in float64 (k_count_band) and the one that
+    classifies in float32 and re-evaluates its guard bands in float64 (k_count_band32, the default): identical results
+    on merged items (binned x unbinned, per-bin thresholds, 2 and 4 edges) and per-bin items, weighted or not."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(321 + 0)
+    P, B = 5, 6
+    ctx.set_option("band_fp32", fp32)
+    try:
+        for weights in ("uu", "wu", "uw", "ww"):
+            c1 = _random_catalog(rng, 9000, P, B, weights[0] == "w", dense_box=1.5)
+            for nb2 in (1, B):
+                c2 = _random_catalog(rng, 11000, P, nb2, weights[1] == "w", dense_box=1.5)
+                jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+                for lim in (oracle.parse_ang_limits(np.array([1.0]) * np.pi / 10800, np.array([9.0]) * np.pi / 10800),
+                            oracle.parse_ang_limits(np.array([0.5, 2.0]) * np.pi / 10800, np.array([3.0, 8.0]) * np.pi / 10800)):
+                    t = np.stack([oracle.thresholds_for(oracle.ang_bins_for(lim * (1.0 + 0.07 * k), None, None)) for k in range(B)])
+                    d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+                    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+                    counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                    assert stats.kernel_used == _lib.KERNEL_BAND
+                    assert np.array_equal(counts, exp_c) and exp_c.sum() > 1000
+                    if weights == "uu":
+                        assert np.array_equal(sums, exp_c.astype(np.float64))
+                    else:
+                        np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+    finally:
+        ctx.set_option("band_fp32", 1)
+
+
 @pytest.mark.parametrize("weights", ["uu", "ww"])
 def test_merged_path_many_edges_and_bins(ctx, weights):
     """Cross-correlation fast path (binned x unbinned) with a fine radial binning (rweight-like, E = 58)

@@ -11,14 +11,15 @@ P, B = 16, 30
 ARCMIN = np.pi / 10800
 
 
-def _box_catalog(seed, n, with_z, side=30.0, weights=None):
+def _box_catalog(seed, n, with_z, width=60.0, height=30.0, weights=None):
+    """BASELINE config #2's footprint: a 60 x 30 degree box, 16 patches on a regular 4 x 4 grid."""
     import yet_another_wizz_amd as yaw
 
     rng = np.random.default_rng(seed)
-    ra = rng.uniform(0.0, side, n)
-    dec = np.rad2deg(np.arcsin(rng.uniform(0.0, np.sin(np.deg2rad(side)), n)))
-    g = np.linspace(side / 8, side * 7 / 8, 4)
-    centers = yaw.AngularCoordinates(np.deg2rad(np.array([(a, d) for a in g for d in g])))
+    ra = rng.uniform(0.0, width, n)
+    dec = np.rad2deg(np.arcsin(rng.uniform(0.0, np.sin(np.deg2rad(height)), n)))
+    ga, gd = np.linspace(width / 8, width * 7 / 8, 4), np.linspace(height / 8, height * 7 / 8, 4)
+    centers = yaw.AngularCoordinates(np.deg2rad(np.array([(a, d) for a in ga for d in gd])))
     z = rng.uniform(0.1, 1.0, n) if with_z else None
     return yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=weights, patch_centers=centers), (ra, dec, z)
 
@@ -47,7 +48,7 @@ def test_three_code_paths_agree_at_1m(setup):
 
     s = setup
     assert s["stats"].candidate_pairs > 9e11 and s["stats"].evaluated_pairs < 0.05 * s["stats"].candidate_pairs
-    assert s["fine"].sum() > 5e7
+    assert s["fine"].sum() > 4e7
     f_filter, st = engine.count_fine(s["lref"], s["lunk"], s["jobs"], s["t"], kernel="filter")
     assert st.evaluated_pairs == st.candidate_pairs
     assert np.array_equal(f_filter, s["fine"])
@@ -208,13 +209,16 @@ def test_headline_size_paths_agree():
 
 
 def test_headline_size_weighted_paths_agree():
-    """The same with per-object weights (w ~ U(0.5, 1.5)): the weighted sums of the strip path against the
-    FP32-filter path on a sample of jobs (different summation orders: 1e-12 relative), run-to-run bit
-    reproducibility of the strip path, and weighted sum / count = <w1 w2> ~ 1."""
+    """The same with per-object weights (w ~ U(0.5, 1.5)) on the DEFAULT path (the band kernel): every slot of the
+    reference's own weighted result (``tools/time_reference.py --weights``: 440 linked pairs x 30 bins, 1e-10 relative),
+    the FP32-filter path on a sample of jobs (another summation order: 1e-12 relative), run-to-run bit
+    reproducibility, and weighted sum / count = <w1 w2> ~ 1."""
+    import os
     import types
 
     import bench
     import yet_another_wizz_amd as yaw
+    from conftest import GOLDEN
     from yet_another_wizz_amd import _lib, engine
     from yet_another_wizz_amd.measurements import angular_plans, threshold_table
 
@@ -225,16 +229,26 @@ def test_headline_size_weighted_paths_agree():
     links = yaw.PatchLinkage.from_catalogs(config, ref, unk)
     jobs = links.get_patch_pairs(ref, unk)
     t = threshold_table(angular_plans(config))
-    s_sweep, st = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
-    s_again, _ = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
-    assert np.array_equal(s_sweep, s_again)
+    s_band, st = engine.count_fine(lref, lunk, jobs, t)
+    assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == 1
+    s_again, _ = engine.count_fine(lref, lunk, jobs, t)
+    assert np.array_equal(s_band, s_again)
+    # the reference, slot by slot
+    slots = np.load(os.path.join(GOLDEN, "fullsize_slots_config3_weighted.npz"))
+    ids, values = slots["DD_ids"], slots["DD_values"]
+    (res,) = links.count_pairs(ref, unk)
+    np.testing.assert_allclose(res.counts.counts[:, ids[:, 0], ids[:, 1]].T, values[:, 0], rtol=1e-10, atol=0)
+    np.testing.assert_allclose(res.sum_weights.sum_weights1, slots["DD_sum_weights1"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(res.sum_weights.sum_weights2, slots["DD_sum_weights2"], rtol=1e-12, atol=0)
     sample = jobs[::40]
     s_filter, _ = engine.count_fine(lref, lunk, sample, t, kernel="filter")
-    np.testing.assert_allclose(s_sweep[::40], s_filter, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(s_band[::40], s_filter, rtol=1e-12, atol=0)
+    s_sweep, _ = engine.count_fine(lref, lunk, sample, t, kernel="sweep")
+    np.testing.assert_allclose(s_band[::40], s_sweep, rtol=1e-12, atol=0)
     ctx = engine.get_context()
     counts, sums, _ = _lib.count_pairs(ctx, engine.device_catalog(lref, ctx), engine.device_catalog(lunk, ctx), sample, t,
-                                       kernel="sweep", want_counts=True, want_sums=True)
-    assert np.array_equal(sums, s_sweep[::40]) and counts.sum() > 2e6
+                                       want_counts=True, want_sums=True)
+    assert np.array_equal(sums, s_band[::40]) and counts.sum() > 2e6
     assert abs(sums.sum() / counts.sum() - 1.0) < 0.01
     ref.drop_layouts()
     unk.drop_layouts()

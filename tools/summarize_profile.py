@@ -44,6 +44,31 @@ for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
                 ns=int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
 with open(os.path.join(out, f"{name}_pmc.json"), "w") as f:
     json.dump(pmc, f, indent=1)
+sys.path.insert(0, root)
+from yet_another_wizz_amd.build import source_sha16  # noqa: E402
+
+sha = source_sha16()
+# SQ counters of the count kernel (tools/profile_bench.sh passes sq1, sq2): last launch of every counter
+sq = {}
+for sub in ("sq1", "sq2"):
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        continue
+    seen, dur, kname = {}, 0, None
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            if "k_count" in row["Kernel_Name"]:
+                seen[row["Counter_Name"]] = float(row["Counter_Value"])
+                dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                kname = row["Kernel_Name"].split("(")[0]
+    if seen:
+        sq[sub] = dict(kernel_ms_under_pmc=dur / 1e6, kernel=kname, **seen)
+if sq:
+    sq["_about"] = ("SQ counters of the count kernel, one launch, two rocprofv3 --pmc passes (tools/profile_bench.sh); "
+                    "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md)")
+    sq["source_sha16"] = sha
+    with open(os.path.join(out, f"{name}_sq_counters.json"), "w") as f:
+        json.dump(sq, f, indent=1)
 mean = lambda rows: sum(r["value"] for r in rows) / max(len(rows), 1)
 if "count:FETCH_SIZE" in pmc and "count:WRITE_SIZE" in pmc:
     traffic = (2.0 * mean(pmc["count:FETCH_SIZE"]) + mean(pmc["count:WRITE_SIZE"])) * 1024.0
@@ -53,7 +78,9 @@ if "count:FETCH_SIZE" in pmc and "count:WRITE_SIZE" in pmc:
     import subprocess
 
     commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    table[key] = dict(bytes=traffic, source=f"profiles/{name}_pmc.json", commit=commit or None,
+    table[key] = dict(bytes=traffic, source=f"profiles/{name}_pmc.json", commit=commit or None, source_sha16=sha,
+                      sq_insts_valu=(sq.get("sq1") or {}).get("SQ_INSTS_VALU"), sq_source=f"profiles/{name}_sq_counters.json" if sq else None,
+                      count_kernel_ns=mean([dict(value=r["ns"]) for r in pmc["count:FETCH_SIZE"]]),
                       date=datetime.date.today().isoformat(),
                       method="(2*FETCH_SIZE + WRITE_SIZE)*1024 per count-kernel launch, rocprofv3 --pmc, one counter per pass")
     with open(tfile, "w") as f:

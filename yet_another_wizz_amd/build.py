@@ -35,6 +35,18 @@ HIPCC_FLAGS = [
 ]
 
 
+def source_sha16() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources and headers: ties a measurement (profiles/pmc_traffic.json)
+    to the code that produced it."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted((*SOURCES, *HEADERS)):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc_path() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
