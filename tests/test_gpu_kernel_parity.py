@@ -667,6 +667,63 @@ def test_borderline_pairs_on_the_strip_paths(ctx, kernel, layout, micro):
         ctx.set_option("tile_r", 0)
 
 
+@pytest.mark.parametrize("theta_deg", [8.0 / 60.0, 3.0, 30.0])
+@pytest.mark.parametrize("grid", ["annulus", "two_scales", "fine"])
+def test_float32_guard_bands_are_decided_exactly(ctx, theta_deg, grid):
+    """The band kernel classifies in float32 and hands evaluations inside a guard band |s32 - t| <= g(t) to the exact
+    float64 predicate. Partners are engineered at theta_edge (1 +- delta) with delta log-uniform in [1e-10, 1e-3] (and
+    exactly on the edge): they fall inside the guard bands, at their borders and just outside, for one annulus, for
+    overlapping scales (4 edges) and for a fine log-spaced grid (25 edges: k_count_band32_fine), from arcminutes (the
+    sqrt(t) term of g dominates) to tens of degrees (the relative term). Bit parity with the oracle."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(int(theta_deg * 1000) + len(grid))
+    B, P, n = 3, 2, 5000
+    theta0 = np.deg2rad(theta_deg)
+    t_rows, edges = [], []
+    for k in range(B):
+        th = theta0 * (1.0 + 0.35 * k)
+        if grid == "annulus":
+            ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th], [th]), None, None)
+        elif grid == "two_scales":
+            ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th, 0.3 * th], [0.4 * th, th]), None, None)
+        else:
+            ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th], [th]), -1.0, 24)
+        edges.append(ab)
+        t_rows.append(oracle.thresholds_for(ab))
+    t = np.stack(t_rows)
+    assert t.shape[1] == {"annulus": 2, "two_scales": 4, "fine": 25}[grid]
+    ra = rng.uniform(-0.01, 0.01, n)
+    dec = rng.uniform(-0.01, 0.01, n)
+    p = np.column_stack(oracle.to_3d(ra % (2 * np.pi), dec))
+    kbin = rng.integers(0, B, n)
+    z1 = 0.1 + (kbin + rng.uniform(0.05, 0.95, n)) * (0.8 / B)
+    edge = np.array([edges[k][rng.integers(0, len(edges[k]))] for k in kbin])
+    delta = np.where(rng.random(n) < 0.1, 0.0, rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-10.0, -3.0, n))
+    ang = edge * (1.0 + delta)
+    q = _tangent_partners(rng, p, ang, rng.normal(size=(n, 3)))
+    ra2, dec2 = np.arctan2(q[:, 1], q[:, 0]), np.arcsin(np.clip(q[:, 2], -1, 1))
+    zedges = np.linspace(0.1, 0.9, B + 1)
+    c1 = oracle.sort_catalog(ra % (2 * np.pi), dec, z1, None, (dec > 0).astype(int), P, zedges, "right")
+    c2 = oracle.sort_catalog(ra2 % (2 * np.pi), dec2, None, None, (dec2 > 0).astype(int), P, None, "right")
+    jobs = np.array([(a, b) for a in range(P) for b in range(P)], dtype=np.int32)
+    exp, _ = oracle.count_jobs(c1, c2, jobs, t)
+    assert exp.sum() > n // 4
+    micro = int(min(max(np.ceil(1.02e6 * np.sqrt(t.max()) / 50.0) * 50.0, 1000), 2000000))
+    try:
+        ctx.set_option("strip_width_micro", micro)
+        d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], None, P, B, c1["off"])
+        d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], None, P, 1, c2["off"])
+        for fp32 in (1, 0):
+            ctx.set_option("band_fp32", fp32)
+            counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band")
+            assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == 1
+            assert np.array_equal(counts, exp), fp32
+    finally:
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+        ctx.set_option("band_fp32", 1)
+
+
 @pytest.mark.parametrize("kernel", ["exact", "filter"])
 def test_weighted_shared_histogram_corner(ctx, kernel):
     """Weighted brute-force counts with more fine bins than per-lane private float64 histograms fit in LDS

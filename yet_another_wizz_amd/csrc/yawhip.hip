@@ -1382,8 +1382,10 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 //     the window is staged from it by LDS-DMA (one dwordx4 per entry) and read back with one ds_read_b128;
 //   * s32 = fma(dz, dz, fma(dy, dy, dx * dx)) on the float32 images, two lane objects per packed instruction
 //     (v_pk_add / v_pk_mul / v_pk_fma_f32: 7 VALU for two evaluations instead of 16 FP64 operations);
-//   * for unit vectors |s32 - s| <= g(t) = 4.2e-7 sqrt(t) + 5e-7 t + 1e-12 around an edge t (rounding of the images to
-//     float32: 2^-24 per coordinate; of the differences; of the three-term sum), so s32 < t - g proves s <= t and
+//   * for unit vectors |s32 - s| <= g(t) = 2.1e-7 sqrt(t) + 5e-7 t + 1e-12 around an edge t (rounding of the images to
+//     float32: 2^-25 per coordinate -- |x| <= 1, and values a hair above 1 round to 1 --, of the differences: 2^-24
+//     relative, hence |error of d_i| <= 6e-8 (1 + |d_i|) and 2 |d| sqrt(3) 6e-8 on the sum of squares; of the three-term
+//     sum: 3 x 2^-24 relative), so s32 < t - g proves s <= t and
 //     s32 > t + g proves s > t. The host turns every edge into the two float32 bounds (thr32, build_thr32);
 //   * an evaluation that lands inside a guard band (~1e-4 of them at the headline) is UNCERTAIN: the wave branches, the
 //     lanes concerned fetch both objects in float64 and apply the exact predicate of the parity contract
@@ -1397,6 +1399,7 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 //   NE  > 2: cumulative counters per edge (s <= t_e), fine bin j = cum[j + 1] - cum[j] at the flush.
 // ------------------------------------------------------------------------------------------------
 constexpr float PAD_COORD32 = 4.0f;
+constexpr double BAND32_GUARD_SQRT = 2.1e-7;  // coefficient of sqrt(t) in the float32 guard g(t), see k_count_band32
 // float32 words per bin of the threshold table: NE == 2: {c, h_in, h_out, 0}; else per edge {t - g, t + g}
 __host__ __device__ constexpr int thr32_width(int ne) { return ne == 2 ? 4 : 2 * ne; }
 // dynamic LDS of a k_count_band32 workgroup (host and device agree through this one function)
@@ -1718,6 +1721,265 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
         }
         if constexpr (WEIGHTED) {
             flush_lanes();
+            __syncthreads();
+            for (int idx = lane; idx < nslots; idx += 64) {
+                partials[(int64_t)it.pot * nslots + idx] = (double)hist[idx];
+                hist[idx] = HistT(0);
+            }
+        } else {
+            flush_counts();
+        }
+        for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
+        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Band kernel for FINE radial grids (separation weights: `resolution` + 1 log-spaced edges per redshift bin,
+// reference src/yaw/catalog/trees.py:107-117,358-360). Items, staging, band search and the float32 distance are
+// k_count_band32's; what differs is how an evaluation finds its fine bin among ~50:
+//   * the edges of a bin are log-spaced, so f = (log2 s32 - log2 t_0) * m puts edge j at f = j (the host checks the
+//     table against this model and passes its worst deviation): the fine bin is floor(f) -- one v_log_f32, one fma, one
+//     floor instead of a six-step binary search through LDS;
+//   * the guess is CERTAIN when the fractional part of f keeps eps(s32) = e0 + e1 / sqrt(s32) away from 0 and 1; eps covers
+//     the model's deviation, the error of the hardware logarithm and the float32 guard g(t) of k_count_band32;
+//   * otherwise (a few 1e-3 of the evaluations) the lane reads the float32 bounds {t_j - g, t_j + g} of the NEAREST edge
+//     j = round(f) from an LDS table and decides between bins j - 1 and j; inside the guard band the exact float64
+//     predicate on the float64 columns decides, against the host's float64 thresholds.
+// Hits go to an LDS histogram [bin][fine bin] with one atomic per evaluation (a miss adds to the lane's dummy cell).
+// Rows of the float32 table (fine32): {m, a = m log2 t_0, e0, e1}, then {t_j - g, t_j + g} per edge.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int fine32_width(int n_edges) { return 4 + 2 * n_edges; }
+__host__ __device__ inline size_t band32_fine_lds(bool weighted, int cap, int nslots, int rows, int n_edges) {
+    return (size_t)3 * (cap + 4) * 4 + (weighted ? (size_t)(cap + 2) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) + 64 * 8 +
+           (size_t)rows * fine32_width(n_edges) * 4 + 48;
+}
+
+template <int R, int CAP, bool WEIGHTED, bool MERGED, bool UNI>
+__global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+                                                          int n_edges, const double *__restrict__ t, const float *__restrict__ fine32,
+                                                          const double *__restrict__ rwin_k, unsigned flush_mask,
+                                                          unsigned long long *__restrict__ out_counts,
+                                                          double *__restrict__ partials,
+                                                          unsigned long long *__restrict__ counters) {
+    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
+    constexpr int HB = WEIGHTED ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    const int nkb = MERGED ? n_bins : 1;
+    const int nf = n_edges - 1;
+    const int nslots = nkb * nf;
+    const int tw = fine32_width(n_edges);
+    const int rows = UNI ? 1 : n_bins;
+    unsigned char *p = lds_dyn;
+    constexpr unsigned COLB = (CAP + 4) * 4;
+    float *stage = reinterpret_cast<float *>(p); p += (size_t)3 * COLB;
+    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 2) * 8;
+    HistT *hist = reinterpret_cast<HistT *>(p); p += (size_t)nslots * sizeof(HistT);
+    p = reinterpret_cast<unsigned char *>(((size_t)p + 15) & ~(size_t)15);
+    double *dummy = reinterpret_cast<double *>(p); p += 64 * 8;  // one cell per lane for misses
+    float *stab = reinterpret_cast<float *>(p);                  // [rows][tw]
+    const int lane = threadIdx.x;
+    const unsigned a_stage = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(stage);
+    const unsigned a_sw = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
+    const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
+    const unsigned a_dummy = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(dummy + lane);
+
+    const unsigned long long n_kept = counters[0];
+    const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
+    for (int e = lane; e < rows * tw; e += 64) stab[e] = fine32[e];
+    unsigned stage_no = 0;
+    for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
+        if ((v >> 3) >= chunk) break;
+        const unsigned long long ticket = (v & 7) * chunk + (v >> 3);
+        if (ticket >= n_kept) continue;
+        const Item it = items[ticket];
+        const int o = item_orient(it), islot = item_slot(it);
+        const DevTab cl = tabs[MERGED ? o : 3 + o], cs = tabs[MERGED ? 3 + o : o];  // lane side, streamed side
+        const int kfix = MERGED ? 0 : islot % n_bins;
+        const float rwin = (float)(rwin_k[kfix] * 1.000001 + 4e-7);
+        int64_t b0 = it.b0[0], nb_total = it.nb[0];
+
+        __syncthreads();
+        auto stage_in = [&](int64_t first, int n) {
+            const gf32p gx = cs.qx + b0 + first, gy = cs.qy + b0 + first, gz = cs.qz + b0 + first;
+#pragma unroll
+            for (int c = 0; c < (CAP + 255) / 256; ++c) {
+                const unsigned e = (unsigned)(c * 256 + 4 * lane);
+                if (e < (unsigned)n) {
+                    __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_stage + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_stage + COLB + c * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_stage + 2 * COLB + c * 1024), 16, 0, 0);
+                }
+            }
+            if (WEIGHTED && cs.w) {
+#pragma unroll
+                for (int c = 0; c < (CAP + 127) / 128; ++c) {
+                    const unsigned e = (unsigned)(c * 128 + 2 * lane);
+                    if (e < (unsigned)n) __builtin_amdgcn_global_load_lds(cs.w + b0 + first + e, lds_ptr(a_sw + c * 1024), 16, 0, 0);
+                }
+            }
+        };
+        stage_in(0, (int)(nb_total < CAP ? nb_total : CAP));
+        float ax[R], ay[R], az[R];
+        double aw[R];
+        int kb[R];
+        int n_own = (int)it.na - lane * R;
+        n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool have = r < n_own;
+            const unsigned ic = have ? (unsigned)(lane * R + r) : 0u;
+            ax[r] = have ? (cl.qx + it.a0)[ic] : PAD_COORD32;
+            ay[r] = have ? (cl.qy + it.a0)[ic] : PAD_COORD32;
+            az[r] = have ? (cl.qz + it.a0)[ic] : PAD_COORD32;
+            kb[r] = MERGED ? (have ? (cl.k + it.a0)[ic] : 0) : 0;
+            aw[r] = (WEIGHTED && cl.w) ? (have ? (cl.w + it.a0)[ic] : 0.0) : (have ? 1.0 : 0.0);
+        }
+        float klo, khi;
+        {
+            const int last_r = n_own > 0 ? n_own - 1 : 0;
+            float u_first = cl.axis == 0 ? ax[0] : (cl.axis == 1 ? ay[0] : az[0]), u_last = u_first;
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                if (r == last_r) u_last = cl.axis == 0 ? ax[r] : (cl.axis == 1 ? ay[r] : az[r]);
+            klo = u_first - rwin;
+            khi = u_last + rwin;
+        }
+        unsigned int nev = 0;
+        auto flush_counts = [&]() {  // LDS histogram -> global result (unweighted)
+#if defined(YAW_FINE_DIAG) && YAW_FINE_DIAG == 5
+            return;  // diagnostics: no flush (wrong counts)
+#endif
+            __syncthreads();
+            for (int idx = lane; idx < nslots; idx += 64) {
+                const unsigned int c = (unsigned int)hist[idx];
+                hist[idx] = HistT(0);
+                if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
+            }
+        };
+        // row of every lane object in the float32 table, its model parameters in registers
+        int trow[R];
+        float pm[R], pa[R], pe0[R], pe1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            trow[r] = (UNI ? 0 : (MERGED ? kb[r] : kfix)) * tw;
+            pm[r] = stab[trow[r]]; pa[r] = stab[trow[r] + 1]; pe0[r] = stab[trow[r] + 2]; pe1[r] = stab[trow[r] + 3];
+        }
+
+        for (int win = 0; win < it.nwin; ++win) {
+        if (win > 0) {
+            b0 = win == 1 ? it.b0[1] : it.b0[2];
+            nb_total = win == 1 ? it.nb[1] : it.nb[2];
+        }
+        for (int64_t st0 = 0; st0 < nb_total; st0 += CAP, ++stage_no) {
+            const int n = (int)(nb_total - st0 < CAP ? nb_total - st0 : CAP);
+            if (st0 > 0 || win > 0) {
+                __syncthreads();
+                stage_in(st0, n);
+            }
+            __syncthreads();
+            if (lane == 0) {
+                stage[n] = PAD_COORD32; stage[COLB / 4 + n] = PAD_COORD32; stage[2 * (COLB / 4) + n] = PAD_COORD32;
+                if (WEIGHTED) sw[n] = 0.0;
+            }
+            if (WEIGHTED && !cs.w)
+                for (int e = lane; e < n; e += 64) sw[e] = 1.0;
+            __syncthreads();
+            const unsigned a_key = a_stage + COLB * (unsigned)cl.axis;
+            const unsigned a_sent = a_key + ((unsigned)n << 2);
+            unsigned ql = a_key - 4u, qh = ql;
+            for (unsigned step = 4u << (31 - __builtin_clz(n)); step >= 4u; step >>= 1) {
+                const unsigned pl = ql + step, ph = qh + step;
+                const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent ? pl : a_sent);
+                const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent ? ph : a_sent);
+                ql = kl < klo ? pl : ql;
+                qh = kh <= khi ? ph : qh;
+            }
+            int lo = (int)((ql + 4u - a_key) >> 2), hi = (int)((qh + 4u - a_key) >> 2);
+            if (n_own == 0) lo = hi = n;
+            const int len = hi - lo;
+            nev += (unsigned int)(len * n_own);
+#if defined(YAW_FINE_DIAG) && YAW_FINE_DIAG == 1
+            const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
+#else
+            const int steps = wave_max_nonneg(len);
+#endif
+
+            unsigned cur = a_stage + ((unsigned)lo << 2);
+            const unsigned last = a_stage + ((unsigned)n << 2);
+            for (int s = 0; s < steps; ++s) {
+                const unsigned a16 = cur < last ? cur : last;
+                cur += 4;
+                const float ex = *(const __attribute__((address_space(3))) float *)(size_t)a16;
+                const float ey = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + COLB);
+                const float ez = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + 2 * COLB);
+                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) << 1) + a_sw) : 1.0;
+                float s32[R], f[R];
+                bool med[R];
+                bool any_med = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float dx = ax[r] - ex, dy = ay[r] - ey, dz = az[r] - ez;
+                    s32[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    f[r] = __builtin_fmaf(__builtin_amdgcn_logf(s32[r]), pm[r], -pa[r]);  // edge j of the object's bin sits at f = j
+                    const float fl = __builtin_floorf(f[r]);
+                    const float eps = __builtin_fmaf(__builtin_amdgcn_rsqf(s32[r]), pe1[r], pe0[r]);
+                    const bool cert = __builtin_fabsf((f[r] - fl) - 0.5f) < 0.5f - eps;  // (false for s32 = 0: f = -inf, eps = inf)
+                    const int g = (int)fl;
+                    const bool fast = cert & ((unsigned)g < (unsigned)nf);
+                    med[r] = !cert & (f[r] > -1.0f) & (f[r] < (float)(nf + 1));
+                    any_med |= med[r];
+                    const unsigned cell = a_hist + ((unsigned)(kb[r] * nf + g) << HB);
+                    if constexpr (WEIGHTED) {
+                        if (fast)
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * ew,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)(fast ? cell : a_dummy), 1u,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+#if defined(YAW_FINE_DIAG) && YAW_FINE_DIAG == 6
+                any_med = false;  // diagnostics: no second look at the evaluations near an edge (wrong counts)
+#endif
+                if (__builtin_amdgcn_ballot_w64(any_med) != 0ull) {
+                    // near an edge of the fine grid: the float32 bounds of that edge decide, the exact predicate inside them
+                    const unsigned eidx = (a16 - a_stage) >> 2;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if (med[r]) {
+                            int j = (int)__builtin_rintf(f[r]);
+                            j = j < 0 ? 0 : (j > nf ? nf : j);
+                            const float tm = stab[trow[r] + 4 + 2 * j], tp = stab[trow[r] + 5 + 2 * j];
+                            int bin = s32[r] < tm ? j - 1 : j;
+                            if (!(s32[r] < tm) && !(s32[r] > tp)) {  // inside the guard band of edge j
+                                bin = -1;
+                                if (eidx < (unsigned)n && r < n_own) {
+                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx);
+                                    const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * n_edges;
+                                    bin = sd <= tk[j] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
+                                    if (bin >= 0 && !(sd > tk[bin])) bin = -1;        // (degenerate tables: equal edges)
+                                    if (bin < nf && bin >= 0 && !(sd <= tk[bin + 1])) bin = -1;
+                                }
+                            }
+                            if ((unsigned)bin < (unsigned)nf) {
+                                const unsigned cell = a_hist + ((unsigned)(kb[r] * nf + bin) << HB);
+                                if constexpr (WEIGHTED)
+                                    (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * ew,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else
+                                    (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, 1u,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                        }
+                    }
+                }
+            }
+            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush_counts();
+        }
+        }
+        if constexpr (WEIGHTED) {
             __syncthreads();
             for (int idx = lane; idx < nslots; idx += 64) {
                 partials[(int64_t)it.pot * nslots + idx] = (double)hist[idx];
@@ -2650,7 +2912,7 @@ struct CallState {
 };
 
 // Float32 bounds of every edge for k_count_band32 (see there): for unit vectors rounded to float32,
-//   |s32 - s| <= g(t) = 4.2e-7 sqrt(t) + 5e-7 t + 1e-12 near s = t,
+//   |s32 - s| <= g(t) = 2.1e-7 sqrt(t) + 5e-7 t + 1e-12 near s = t,
 // so s32 < t - g proves s <= t and s32 > t + g proves s > t; in between the kernel evaluates in float64.
 //   n_edges == 2: {c, h_in, h_out, 0}: |s32 - c| < h_in proves t0 < s <= t1, |s32 - c| >= h_out proves the opposite
 //                 (both widths carry the rounding of the float32 subtraction);
@@ -2658,7 +2920,7 @@ struct CallState {
 std::vector<float> build_thr32(const double *t, int n_bins, int n_edges) {
     auto down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; };
     auto up = [](double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; };
-    auto guard = [](double te) { return 4.2e-7 * std::sqrt(te) + 5e-7 * te + 1e-12; };
+    auto guard = [](double te) { return BAND32_GUARD_SQRT * std::sqrt(te) + 5e-7 * te + 1e-12; };
     const int tw = thr32_width(n_edges);
     std::vector<float> out((size_t)n_bins * tw, 0.f);
     for (int k = 0; k < n_bins; ++k) {
@@ -2680,6 +2942,42 @@ std::vector<float> build_thr32(const double *t, int n_bins, int n_edges) {
                 row[2 * e] = down(tk[e] - g);
                 row[2 * e + 1] = up(tk[e] + g);
             }
+        }
+    }
+    return out;
+}
+
+// Float32 table of k_count_band32_fine (see there), one row per redshift bin: {m, a, e0, e1}, then {t_j - g, t_j + g} per edge.
+// Empty when the edges of some bin do not follow the log-spaced model closely enough for float32 (the caller then counts
+// with the float64 band kernel): deviation above 0.05 fine bins, a guard wider than a fifth of a fine bin, t_0 = 0.
+std::vector<float> build_fine32(const double *t, int n_bins, int n_edges) {
+    auto down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; };
+    auto up = [](double v) { float f = (float)v; if ((double)f < v) f = nextafterf(f, INFINITY); return f; };
+    auto guard = [](double te) { return BAND32_GUARD_SQRT * std::sqrt(te) + 5e-7 * te + 1e-12; };
+    const int tw = fine32_width(n_edges), nf = n_edges - 1;
+    std::vector<float> out((size_t)n_bins * tw, 0.f);
+    for (int k = 0; k < n_bins; ++k) {
+        const double *tk = t + (size_t)k * n_edges;
+        if (!(tk[0] > 1e-12) || !(tk[nf] > tk[0])) return {};
+        const double l0 = std::log2(tk[0]), l1 = std::log2(tk[nf]);
+        const double m = (double)nf / (l1 - l0), a = l0 * m;
+        double dev = 0.0;
+        for (int j = 0; j <= nf; ++j) {
+            if (j > 0 && !(tk[j] > tk[j - 1])) return {};
+            dev = std::max(dev, std::fabs((std::log2(tk[j]) - l0) * m - (double)j));
+        }
+        // error of the device's f: hardware log2 (1 ulp of a result below 64), float32 images of m and a, the fma
+        const double dev_f = m * (1e-5 + 6e-8 * 64.0) + 2.0 * 6e-8 * std::fabs(a) + 4e-5 + 6e-8 * (nf + 2);
+        const double per_s = 1.05 * m / std::log(2.0);  // d f / (d s / s), with room for the second order
+        const double e0 = dev + dev_f + per_s * (5e-7 + 1e-12 / tk[0]);
+        const double e1 = per_s * 1.1 * BAND32_GUARD_SQRT;  // x 1.1: eps is taken at s32, up to a fifth of a bin away from the edge
+        if (dev > 0.05 || e0 + e1 / std::sqrt(tk[0]) > 0.2) return {};
+        float *row = &out[(size_t)k * tw];
+        row[0] = (float)m; row[1] = (float)a; row[2] = up(e0); row[3] = up(e1);
+        for (int j = 0; j <= nf; ++j) {
+            const double g = guard(tk[j]);
+            row[4 + 2 * j] = down(tk[j] - g);
+            row[5 + 2 * j] = up(tk[j] + g);
         }
     }
     return out;
@@ -2811,7 +3109,13 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const bool want32 = band && strip_items && unit && n_edges <= 4 && ctx->band_fp32 != 0 &&
                         band32_lds(weighted_any, BCAP_MID, (merged ? n_bins : 1) * nf, merged && !uniform_t ? n_bins : 0, n_edges) <=
                             (size_t)ctx->lds_limit;
-    bool swap = want32 && merged;
+    // ... and the fine radial grids of separation weights (k_count_band32_fine), when their edges follow the log-spaced model
+    std::vector<float> fine32;
+    if (band && strip_items && unit && n_edges > 4 && ctx->band_fp32 != 0 &&
+        band32_fine_lds(weighted_any, BCAP_MID, (merged ? n_bins : 1) * nf, uniform_t ? 1 : n_bins, n_edges) <= (size_t)ctx->lds_limit)
+        fine32 = build_fine32(t, n_bins, n_edges);
+    const bool want_fine = !fine32.empty();
+    bool swap = (want32 || want_fine) && merged;
     const yawhip_catalog *c_lane = swap ? c1 : c2, *c_strm = swap ? c2 : c1;
     const StripLayout *const *LL = swap ? L1 : L2, *const *LS = swap ? L2 : L1;  // lane side, streamed side
     if (auto_pick && band && unit) {
@@ -2832,8 +3136,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             band = false;
         }
     }
-    const bool band32 = want32 && band;
-    if (!band32 && swap) {  // the sweep kernel streams c1 past lane tiles of c2
+    const bool band32 = want32 && band, band_fine = want_fine && band;
+    if (!band32 && !band_fine && swap) {  // the sweep kernel streams c1 past lane tiles of c2
         swap = false;
         c_lane = c2; c_strm = c1; LL = L2; LS = L1;
     }
@@ -3044,7 +3348,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const size_t o_t = take((size_t)n_bins * n_edges * sizeof(double));
     const size_t o_dthr = take((size_t)3 * n_bins * sizeof(float));
     const size_t o_rwin = take((size_t)n_bins * sizeof(double));
-    const std::vector<float> thr32 = band32 ? build_thr32(t, n_bins, n_edges) : std::vector<float>();
+    const std::vector<float> thr32 = band32 ? build_thr32(t, n_bins, n_edges) : (band_fine ? fine32 : std::vector<float>());
     const size_t o_thr32 = take(thr32.size() * sizeof(float));
     const size_t o_tabs = take(sizeof h_tabs);
     HIP_TRY(ctx->in.reserve(off_in));
@@ -3258,7 +3562,43 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
 #undef YAW_LAUNCH_BAND
             return hipGetLastError();
         };
-        auto launch_band = [&](bool wgt) -> hipError_t { return band32 ? launch_band32(wgt) : launch_band64(wgt); };
+        const size_t lds_fine = band32_fine_lds(weighted_any, cap, lean_bins * nf, uniform_t ? 1 : n_bins, n_edges);
+        auto launch_fine = [&](bool wgt) -> hipError_t {
+#define YAW_LAUNCH_FINE(RR, CC, WW, MM, UU)                                                                           \
+    do {                                                                                                              \
+        auto kern = k_count_band32_fine<RR, CC, WW, MM, UU>;                                                          \
+        if (lds_fine > 64 * 1024) {                                                                                   \
+            hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fine);           \
+            if (ea != hipSuccess) return ea;                                                                          \
+        }                                                                                                             \
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_fine, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
+                           n_bins, n_edges, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, ctx->d_counts.ptr, \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
+    } while (0)
+#define YAW_LAUNCH_FINE_R(WW, MM, UU)                                                                                 \
+    do {                                                                                                              \
+        if (R == 1) YAW_LAUNCH_FINE(1, BCAP, WW, MM, UU);                                                             \
+        else if (R == 2 && cap == BCAP) YAW_LAUNCH_FINE(2, BCAP, WW, MM, UU);                                         \
+        else if (R == 2) YAW_LAUNCH_FINE(2, BCAP_MID, WW, MM, UU);                                                    \
+        else YAW_LAUNCH_FINE(4, BCAP_MID, WW, MM, UU);                                                                \
+    } while (0)
+#define YAW_LAUNCH_FINE_M(WW)                                                                                         \
+    do {                                                                                                              \
+        if (!merged && uniform_t) YAW_LAUNCH_FINE_R(WW, false, true);                                                 \
+        else if (!merged) YAW_LAUNCH_FINE_R(WW, false, false);                                                        \
+        else if (uniform_t) YAW_LAUNCH_FINE_R(WW, true, true);                                                        \
+        else YAW_LAUNCH_FINE_R(WW, true, false);                                                                      \
+    } while (0)
+            if (wgt) YAW_LAUNCH_FINE_M(true); else YAW_LAUNCH_FINE_M(false);
+#undef YAW_LAUNCH_FINE_M
+#undef YAW_LAUNCH_FINE_R
+#undef YAW_LAUNCH_FINE
+            return hipGetLastError();
+        };
+        auto launch_band = [&](bool wgt) -> hipError_t {
+            return band32 ? launch_band32(wgt) : (band_fine ? launch_fine(wgt) : launch_band64(wgt));
+        };
         if (run_unweighted) {
             HIP_TRY(launch_band(false));
             ++launches;
