@@ -41,11 +41,12 @@ print(f"layouts + linkage in {time.perf_counter() - t0:.1f} s", flush=True)
 total = 0.0
 for name, l1, l2, auto in (("DD", ld, ld, True), ("DR", ld, lr, False), ("RR", lr, lr, True)):
     jobs = links.get_patch_pairs(data, None if auto else rand)
-    for kern in ("auto", "filter") if (name == "DD" and n <= 2_000_000) else ("auto", "sweep"):
+    for kern in ("auto", "filter") if (name == "DD" and n <= 2_000_000) else ("auto", "sweep", "band"):
         for rep in range(2):
             fine, st = engine.count_fine(l1, l2, jobs, t, kernel=kern)
         if kern == "auto":
             total += st.kernel_ms
+        kern = f"{kern}->{st.kernel_used}"
         print(f"{name} {kern}: jobs={len(jobs)} cand={st.candidate_pairs:.3e} eval={st.evaluated_pairs:.3e} kernel_ms={st.kernel_ms:.2f} "
               f"count_ms={st.count_ms:.2f} mode={st.layout_mode} rate={st.candidate_pairs/st.kernel_ms/1e6:.1f} Gpairs/s found={fine.sum():.6g} wgs={st.n_workgroups}", flush=True)
 print(f"DD+DR+RR kernels: {total:.2f} ms", flush=True)

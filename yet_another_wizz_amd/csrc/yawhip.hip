@@ -1194,7 +1194,8 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
                 __syncthreads();  // every lane is done with the previous stage
                 stage_in(st0, n);
             }
-            __syncthreads();  // the stage has landed (the compiler drains the LDS-DMA in front of the barrier)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stage has landed: only the wave's own vmcnt orders LDS reads behind its LDS-DMA
+            __syncthreads();
             if (lane == 0) {  // sentinel behind the stage: lanes whose band has ended read it; it is beyond every edge
                 sx[n] = PAD_COORD; sy[n] = PAD_COORD; sz[n] = PAD_COORD;
                 if (WEIGHTED) sw[n] = 0.0;
@@ -1404,7 +1405,7 @@ constexpr double BAND32_GUARD_SQRT = 2.1e-7;  // coefficient of sqrt(t) in the f
 __host__ __device__ constexpr int thr32_width(int ne) { return ne == 2 ? 4 : 2 * ne; }
 // dynamic LDS of a k_count_band32 workgroup (host and device agree through this one function)
 __host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots, int thr_rows, int ne) {
-    return (size_t)3 * (cap + 4) * 4 + (weighted ? (size_t)(cap + 2) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) +
+    return (size_t)3 * (cap + 4) * 4 + (weighted ? (size_t)(cap + 4) * 8 : 0) + (size_t)nslots * (weighted ? 8 : 4) +
            (size_t)thr_rows * thr32_width(ne) * 4 + 32;
 }
 
@@ -1418,14 +1419,29 @@ __device__ __attribute__((noinline)) double band32_exact_s(gf64p lx, gf64p ly, g
     return sxy + zz;
 }
 
+#ifndef YAW_B32_CAP
+#define YAW_B32_CAP 320
+#endif
+#ifndef YAW_B32_CAP_BIG
+#define YAW_B32_CAP_BIG 512
+#endif
+// Stage of k_count_band32 (entries, 12 bytes each + 8 with weights). 320 holds two windows of a typical lane tile (128 objects
+// at equal densities: ~142 entries each) -- measured 192 / 288 / 320 / 448 at the headline: 0.367 / 0.355 / 0.350 / 0.360 ms,
+// weighted 0.521 / 0.519 / 0.511 / 0.556, RR of config #4 4.65 / 4.44 / 4.41 / 4.89 (the larger the stage, the fewer workgroups
+// a CU holds). The big one is for lane tiles whose single window would not fit (denser streamed side, four objects per lane).
+constexpr int B32_CAP = YAW_B32_CAP;
+constexpr int B32_CAP_BIG = YAW_B32_CAP_BIG;
+constexpr int B32_MAX_CHUNKS = 3;  // windows (or pieces of one) staged together in one round of k_count_band32
+
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
 __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED && NE == 2 && UNI ? 7 : 1))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                      const double *__restrict__ t, const float *__restrict__ thr32,
-                                                     const double *__restrict__ rwin_k, unsigned flush_mask,
+                                                     const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
                                                      unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials,
                                                      unsigned long long *__restrict__ counters) {
     static_assert(NE >= 2 && NE <= 4, "edges per bin");
+    static_assert(CAP % 4 == 0, "stage capacity");
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int NC = NE == 2 ? 1 : NE;     // counters per lane object: hits of the annulus, or s <= t_e per edge
     constexpr int NF = NE - 1;               // fine bins per redshift bin
@@ -1435,9 +1451,9 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
     const int nkb = MERGED ? n_bins : 1;
     const int nslots = nkb * NF;
     unsigned char *p = lds_dyn;
-    constexpr unsigned COLB = (CAP + 4) * 4;  // bytes of one staged float32 column: CAP entries, the sentinel, the tail of a 16-byte DMA
+    constexpr unsigned COLB = (CAP + 4) * 4;  // bytes of one staged float32 column
     float *stage = reinterpret_cast<float *>(p); p += (size_t)3 * COLB;  // columns x, y, z
-    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 2) * 8;
+    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 4) * 8;
     HistT *hist = reinterpret_cast<HistT *>(p); p += (size_t)nslots * sizeof(HistT);
     p = reinterpret_cast<unsigned char *>(((size_t)p + 15) & ~(size_t)15);
     float *sthr = reinterpret_cast<float *>(p);  // [n_bins][TW] when LANE_THR
@@ -1451,42 +1467,79 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
     for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
     if (LANE_THR)
         for (int e = lane; e < n_bins * TW; e += 64) sthr[e] = thr32[e];
-    unsigned stage_no = 0;
+    unsigned round_no = 0;
     for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
         if ((v >> 3) >= chunk) break;
         const unsigned long long ticket = (v & 7) * chunk + (v >> 3);
         if (ticket >= n_kept) continue;  // short last eighth
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
-        const DevTab cl = tabs[MERGED ? o : 3 + o], cs = tabs[MERGED ? 3 + o : o];  // lane side, streamed side
+        const DevTab cl = tabs[swap ? o : 3 + o], cs = tabs[swap ? 3 + o : o];  // lane side, streamed side
         const int kfix = MERGED ? 0 : islot % n_bins;
         // half width of the u-window in float32: sqrt(t_max) widened by the rounding of both keys and of the subtraction
         const float rwin = (float)(rwin_k[kfix] * 1.000001 + 4e-7);
-        int64_t b0 = it.b0[0], nb_total = it.nb[0];
 
-        __syncthreads();  // the previous item of this workgroup has left the LDS
-        auto stage_in = [&](int64_t first, int n) {
-            // four entries of one column per lane and instruction (16 bytes; the last lane may run up to three entries past
-            // the window: into the next run, and into the column's slack in LDS)
-            const gf32p gx = cs.qx + b0 + first, gy = cs.qy + b0 + first, gz = cs.qz + b0 + first;
+        // The windows of an item are staged in ROUNDS: as many whole windows as fit the stage together (all three of a
+        // typical item: one wait for the LDS-DMA instead of three, and the band searches of the windows run in lockstep);
+        // a window longer than the stage goes through it alone, CAP - 4 entries at a time. A chunk = (first streamed
+        // object, entries, first entry of the stage it occupies); every chunk is followed by its own sentinel entry.
+        int win = 0;            // next window of the item
+        int64_t win_off = 0;    // entries of it already staged
+        int64_t cb[B32_MAX_CHUNKS];
+        int cn[B32_MAX_CHUNKS], co[B32_MAX_CHUNKS];
+        int nch = 0;
+        auto next_round = [&]() {
+            nch = 0;
+            int used = 0;
 #pragma unroll
-            for (int c = 0; c < (CAP + 255) / 256; ++c) {
-                const unsigned e = (unsigned)(c * 256 + 4 * lane);
-                if (e < (unsigned)n) {
-                    __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_stage + c * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_stage + COLB + c * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_stage + 2 * COLB + c * 1024), 16, 0, 0);
-                }
-            }
-            if (WEIGHTED && cs.w) {
-#pragma unroll
-                for (int c = 0; c < (CAP + 127) / 128; ++c) {
-                    const unsigned e = (unsigned)(c * 128 + 2 * lane);
-                    if (e < (unsigned)n) __builtin_amdgcn_global_load_lds(cs.w + b0 + first + e, lds_ptr(a_sw + c * 1024), 16, 0, 0);
+            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
+                cb[c] = 0; cn[c] = 0; co[c] = 0;
+                if (win < it.nwin && nch == c) {
+                    const int64_t wb = win == 0 ? it.b0[0] : (win == 1 ? it.b0[1] : it.b0[2]);
+                    const int64_t rem = (int64_t)(win == 0 ? it.nb[0] : (win == 1 ? it.nb[1] : it.nb[2])) - win_off;
+                    if (rem + 1 <= (int64_t)(CAP - used)) {           // the rest of the window and its sentinel fit
+                        cb[c] = wb + win_off; cn[c] = (int)rem; co[c] = used;
+                        used += ((int)rem + 1 + 3) & ~3;
+                        ++win; win_off = 0; ++nch;
+                    } else if (c == 0) {                               // alone in the stage, a piece at a time
+                        cb[c] = wb + win_off; cn[c] = CAP - 4; co[c] = 0;
+                        used = CAP;
+                        win_off += CAP - 4; ++nch;
+                    }
                 }
             }
         };
-        stage_in(0, (int)(nb_total < CAP ? nb_total : CAP));
+        auto issue_round = [&]() {
+#pragma unroll
+            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
+                if (c < nch) {
+                    // four entries of one column per lane and instruction (16 bytes; the last lane may run up to three entries
+                    // past the chunk: into the next run of the catalogue, and into the chunk's padding in LDS)
+                    const gf32p gx = cs.qx + cb[c], gy = cs.qy + cb[c], gz = cs.qz + cb[c];
+                    const unsigned a_c = a_stage + ((unsigned)co[c] << 2);
+#pragma unroll
+                    for (int k = 0; k < (CAP + 255) / 256; ++k) {
+                        const unsigned e = (unsigned)(k * 256 + 4 * lane);
+                        if (e < (unsigned)cn[c]) {
+                            __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_c + k * 1024), 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_c + COLB + k * 1024), 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_c + 2 * COLB + k * 1024), 16, 0, 0);
+                        }
+                    }
+                    if (WEIGHTED && cs.w) {
+#pragma unroll
+                        for (int k = 0; k < (CAP + 127) / 128; ++k) {
+                            const unsigned e = (unsigned)(k * 128 + 2 * lane);
+                            if (e < (unsigned)cn[c])
+                                __builtin_amdgcn_global_load_lds(cs.w + cb[c] + e, lds_ptr(a_sw + ((unsigned)co[c] << 3) + k * 1024), 16, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        __syncthreads();  // the previous item of this workgroup has left the LDS
+        next_round();
+        issue_round();
         // lane objects while the stage is in flight: R NEIGHBOURING objects of the u-sorted tile per lane
         f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
         float ax[R], ay[R], az[R];
@@ -1571,43 +1624,57 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
             }
         };
 
-        for (int win = 0; win < it.nwin; ++win) {
-        if (win > 0) {
-            b0 = win == 1 ? it.b0[1] : it.b0[2];
-            nb_total = win == 1 ? it.nb[1] : it.nb[2];
-        }
-        for (int64_t st0 = 0; st0 < nb_total; st0 += CAP, ++stage_no) {
-            const int n = (int)(nb_total - st0 < CAP ? nb_total - st0 : CAP);
-            if (st0 > 0 || win > 0) {
-                __syncthreads();  // every lane is done with the previous stage
-                stage_in(st0, n);
-            }
-            __syncthreads();  // the stage has landed (the compiler drains the LDS-DMA in front of the barrier)
-            if (lane == 0) {  // sentinel behind the stage: beyond every edge of every lane object
-                stage[n] = PAD_COORD32; stage[COLB / 4 + n] = PAD_COORD32; stage[2 * (COLB / 4) + n] = PAD_COORD32;
-                if (WEIGHTED) sw[n] = 0.0;
-            }
-            if (WEIGHTED && !cs.w)
-                for (int e = lane; e < n; e += 64) sw[e] = 1.0;
+        for (;; ++round_no) {
+            // The round has landed: nothing but the issuing wave's own vmcnt orders an LDS read behind a pending LDS-DMA. The
+            // wait is spelled out -- in a single-wave workgroup __syncthreads() is no barrier instruction, and on this loop's
+            // back edge hipcc did not put a vmcnt wait in front of the LDS accesses by itself (counts came out wrong now and then).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            // band of the lane inside this stage: [lo, hi) = entries with klo <= key <= khi, by two branch-free binary
-            // searches on LDS byte addresses (q = address of entry lo - 1; a probe beyond the stage is clamped onto the
-            // sentinel, whose key 4.0 fails both comparisons)
-            const unsigned a_key = a_stage + COLB * (unsigned)cl.axis;
-            const unsigned a_sent = a_key + ((unsigned)n << 2);
-            unsigned ql = a_key - 4u, qh = ql;
+            if (lane < nch) {  // a sentinel behind every chunk: beyond every edge of every lane object
+                const int at = (lane == 0 ? co[0] + cn[0] : (lane == 1 ? co[1] + cn[1] : co[2] + cn[2]));
+                stage[at] = PAD_COORD32; stage[COLB / 4 + at] = PAD_COORD32; stage[2 * (COLB / 4) + at] = PAD_COORD32;
+                if (WEIGHTED) sw[at] = 0.0;
+            }
+            if (WEIGHTED && !cs.w) {
+#pragma unroll
+                for (int c = 0; c < B32_MAX_CHUNKS; ++c)
+                    if (c < nch)
+                        for (int e = lane; e < cn[c]; e += 64) sw[co[c] + e] = 1.0;
+            }
+            __syncthreads();
+            // bands of the lane inside the chunks: [lo, hi) = entries with klo <= key <= khi, by branch-free binary searches
+            // on LDS byte addresses, all chunks in lockstep (q = address of entry lo - 1; a probe beyond a chunk is clamped
+            // onto its sentinel, whose key 4.0 fails both comparisons -- so one step schedule serves chunks of any length)
+            unsigned a_key[B32_MAX_CHUNKS], a_sent[B32_MAX_CHUNKS], ql[B32_MAX_CHUNKS], qh[B32_MAX_CHUNKS];
+            int n_max = 1;
+#pragma unroll
+            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
+                a_key[c] = a_stage + COLB * (unsigned)cl.axis + ((unsigned)co[c] << 2);
+                a_sent[c] = a_key[c] + ((unsigned)cn[c] << 2);
+                ql[c] = qh[c] = a_key[c] - 4u;
+                n_max = cn[c] > n_max ? cn[c] : n_max;
+            }
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
             for (unsigned step = 0; step >= 4u; step >>= 1) {  // diagnostics: no search either
 #else
-            for (unsigned step = 4u << (31 - __builtin_clz(n)); step >= 4u; step >>= 1) {  // largest power of two <= n
+            for (unsigned step = 4u << (31 - __builtin_clz(n_max)); step >= 4u; step >>= 1) {  // largest power of two <= n_max
 #endif
-                const unsigned pl = ql + step, ph = qh + step;
-                const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent ? pl : a_sent);
-                const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent ? ph : a_sent);
-                ql = kl < klo ? pl : ql;    // entries [0, lo) have key <  klo
-                qh = kh <= khi ? ph : qh;   // entries [0, hi) have key <= khi
+#pragma unroll
+                for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
+                    if (c < nch) {
+                        const unsigned pl = ql[c] + step, ph = qh[c] + step;
+                        const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent[c] ? pl : a_sent[c]);
+                        const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent[c] ? ph : a_sent[c]);
+                        ql[c] = kl < klo ? pl : ql[c];    // entries [0, lo) have key <  klo
+                        qh[c] = kh <= khi ? ph : qh[c];   // entries [0, hi) have key <= khi
+                    }
+                }
             }
-            int lo = (int)((ql + 4u - a_key) >> 2), hi = (int)((qh + 4u - a_key) >> 2);
+#pragma unroll
+            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
+            if (c < nch) {
+            const int n = cn[c];
+            int lo = (int)((ql[c] + 4u - a_key[c]) >> 2), hi = (int)((qh[c] + 4u - a_key[c]) >> 2);
             if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
             const int len = hi - lo;
             nev += (unsigned int)(len * n_own);
@@ -1617,39 +1684,24 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
             const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
 #endif
 
-            unsigned cur = a_stage + ((unsigned)lo << 2);
-            const unsigned last = a_stage + ((unsigned)n << 2);
+            const unsigned a_chunk = a_stage + ((unsigned)co[c] << 2);
+            unsigned cur = a_chunk + ((unsigned)lo << 2);
+            const unsigned last = a_chunk + ((unsigned)n << 2);
             // One entry per trip: three 4-byte reads from columns a fixed distance apart (lanes read nearly consecutive words
-            // of a column). The reads of the NEXT trip are issued before this trip's arithmetic (YAW_B32_PREFETCH).
-            struct Entry { float x, y, z; double w; unsigned a; };
-            auto read_entry = [&](unsigned at) {
-                Entry e;
-                e.a = at < last ? at : last;
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -1
-                e.x = klo; e.y = khi; e.z = klo;  // diagnostics: the walk's arithmetic without its LDS reads (wrong counts)
-                asm volatile("" : "+v"(e.x), "+v"(e.y), "+v"(e.z));
-#else
-                e.x = *(const __attribute__((address_space(3))) float *)(size_t)e.a;
-                e.y = *(const __attribute__((address_space(3))) float *)(size_t)(e.a + COLB);
-                e.z = *(const __attribute__((address_space(3))) float *)(size_t)(e.a + 2 * COLB);
-#endif
-                e.w = WEIGHTED ? lds_f64(((e.a - a_stage) << 1) + a_sw) : 1.0;
-                return e;
-            };
-#if YAW_B32_PREFETCH
-            Entry nxt = read_entry(cur);
-            cur += 4;
-#endif
+            // of a column).
             for (int s = 0; s < steps; ++s) {
-#if YAW_B32_PREFETCH
-                const Entry en = nxt;
-                nxt = read_entry(cur);  // (one read past the last trip: clamped onto the sentinel)
-#else
-                const Entry en = read_entry(cur);
-#endif
+                const unsigned a16 = cur < last ? cur : last;
                 cur += 4;
-                const unsigned a16 = en.a;
-                const double ew = en.w;
+                struct { float x, y, z; } en;
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -1
+                en.x = klo; en.y = khi; en.z = klo;  // diagnostics: the walk's arithmetic without its LDS reads (wrong counts)
+                asm volatile("" : "+v"(en.x), "+v"(en.y), "+v"(en.z));
+#else
+                en.x = *(const __attribute__((address_space(3))) float *)(size_t)a16;
+                en.y = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + COLB);
+                en.z = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + 2 * COLB);
+#endif
+                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) << 1) + a_sw) : 1.0;
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -2
                 cnt[0][0] += __float_as_uint(en.x) ^ __float_as_uint(en.y) ^ __float_as_uint(en.z);  // diagnostics: the LDS reads alone
                 continue;
@@ -1692,11 +1744,11 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                 }
                 if (any_mask != 0ull) {
                     // inside a guard band: the exact float64 predicate on the float64 columns decides (rare)
-                    const unsigned eidx = (a16 - a_stage) >> 2;
+                    const unsigned eidx = (a16 - a_chunk) >> 2;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx);
+                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx);
                             const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
                             if constexpr (NE == 2) {
                                 const bool in = sd > tk[0] && sd <= tk[1];
@@ -1715,10 +1767,16 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                     }
                 }
             }
+            }
+            }
             // a lane counter grows by at most one per trip, the LDS cell by 64 R per trip: flush before 2^32
-            if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush_counts();
+            if (!WEIGHTED && (round_no & flush_mask) == flush_mask) flush_counts();
+            if (win >= it.nwin) break;
+            __syncthreads();  // every lane is done with this round's stage
+            next_round();
+            issue_round();
         }
-        }
+        ++round_no;
         if constexpr (WEIGHTED) {
             flush_lanes();
             __syncthreads();
@@ -1878,6 +1936,7 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                 __syncthreads();
                 stage_in(st0, n);
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stage has landed (see k_count_band32)
             __syncthreads();
             if (lane == 0) {
                 stage[n] = PAD_COORD32; stage[COLB / 4 + n] = PAD_COORD32; stage[2 * (COLB / 4) + n] = PAD_COORD32;
@@ -2686,8 +2745,9 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         return YAWHIP_OK;
     }
     if (!strcmp(key, "band_cap")) {
-        if (value != 0 && value != BCAP && value != BCAP_MID)
-            return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 192 or 288");
+        if (value != 0 && value != BCAP && value != BCAP_MID && value != B32_CAP && value != B32_CAP_BIG)
+            return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 192 or 288 (float64 / fine-grid band kernels), %d or %d (float32 band kernel)",
+                        B32_CAP, B32_CAP_BIG);
         ctx->band_cap = (int)value;
         return YAWHIP_OK;
     }
@@ -3186,12 +3246,19 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     }
     if (band && R == 0) R = 2;
     // stage capacity of the band kernel: the smallest compiled one that holds a whole window (see BCAP_MID)
-    int cap = ctx->band_cap;
+    int cap = ctx->band_cap == BCAP || ctx->band_cap == BCAP_MID ? ctx->band_cap : 0;
     if (band && cap == 0) cap = R >= 4 || est_window > 0.95 * BCAP ? BCAP_MID : BCAP;
     if (band) {  // combinations that are compiled
         if (R == 1) cap = BCAP;
         if (R == 4 && cap == BCAP) cap = BCAP_MID;
     }
+    int cap32 = ctx->band_cap == B32_CAP || ctx->band_cap == B32_CAP_BIG ? ctx->band_cap
+                                                                         : (est_window > 0.75 * (B32_CAP - 4) ? B32_CAP_BIG : B32_CAP);
+    // (0.75: window lengths scatter around the estimate, and a window cut in two costs more than a larger stage -- 50M x 50M
+    // with windows of ~265 entries: 21.0 ms in the 320-entry stage, 18.3 ms in a 448-entry one)
+    if (R == 1) cap32 = B32_CAP;      // combinations that are compiled
+    if (R >= 4) cap32 = B32_CAP_BIG;
+    if (band32) cap = cap32;  // (the fine-grid kernel still stages window by window, with the capacities of k_count_band)
     const int64_t tile = (int64_t)(lean ? MWG : WG) * R;
     const int lean_bins = merged ? n_bins : 1;
     const size_t lds_merged = 2 * MSTAGE * sizeof(ObjF) + (size_t)lean_bins * n_edges * sizeof(double) +
@@ -3496,15 +3563,15 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             if (ea != hipSuccess) return ea;                                                                          \
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band32, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
-                           n_bins, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, ctx->d_counts.ptr,    \
+                           n_bins, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, swap ? 1 : 0, ctx->d_counts.ptr, \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
     } while (0)
 #define YAW_LAUNCH_B32_R(WW, NN, MM, UU)                                                                              \
     do {                                                                                                              \
-        if (R == 1) YAW_LAUNCH_B32(1, BCAP, WW, NN, MM, UU);                                                          \
-        else if (R == 2 && cap == BCAP) YAW_LAUNCH_B32(2, BCAP, WW, NN, MM, UU);                                      \
-        else if (R == 2) YAW_LAUNCH_B32(2, BCAP_MID, WW, NN, MM, UU);                                                 \
-        else YAW_LAUNCH_B32(4, BCAP_MID, WW, NN, MM, UU);                                                             \
+        if (R == 1) YAW_LAUNCH_B32(1, B32_CAP, WW, NN, MM, UU);                                                       \
+        else if (R == 2 && cap == B32_CAP) YAW_LAUNCH_B32(2, B32_CAP, WW, NN, MM, UU);                                \
+        else if (R == 2) YAW_LAUNCH_B32(2, B32_CAP_BIG, WW, NN, MM, UU);                                              \
+        else YAW_LAUNCH_B32(4, B32_CAP_BIG, WW, NN, MM, UU);                                                          \
     } while (0)
 #define YAW_LAUNCH_B32_M(WW, NN)                                                                                      \
     do {                                                                                                              \
