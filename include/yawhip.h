@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define YAWHIP_ABI_VERSION 3
+#define YAWHIP_ABI_VERSION 4
 
 typedef enum yawhip_status {
     YAWHIP_OK = 0,
@@ -68,6 +68,11 @@ typedef struct yawhip_stats {
                                   1 = (patch, strip) runs with all bins merged (binned x unbinned), 3 = (patch, bin,
                                   strip) runs (binned x binned, dense catalogues)                       */
     int32_t n_orientations;    /* strip layouts: how many of the three orientations the jobs used (ABI >= 3) */
+    int64_t exact_reevaluations; /* band kernel, float32 classification: evaluations that fell into a guard band of an edge
+                                  and were decided by the exact float64 predicate (ABI >= 4)                  */
+    int32_t band_variant;      /* which band kernel ran (ABI >= 4): 0 none, 64 every entry in float64, 32 float32 classes +
+                                  exact guard bands, 33 the same for fine log-spaced radial grids             */
+    int32_t reserved_;
 } yawhip_stats;
 
 const char *yawhip_last_error(void);
@@ -95,8 +100,8 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *                       histogram while they add to the same output slot (-1 = default: 1 item; larger batches unbalance clustered data)
  *   "hist_copies_log2"  band kernel: log2 of the copies of its LDS histogram (-1 = auto: 4 copies for few slots, up to 16
  *                       for per-bin items or when neighbouring objects of a binned catalogue mostly share their bin; 0..6)
- *   "band_cap"          entries per LDS stage of the band kernel (0 = auto: 192, or 288 when a lane tile's window is
- *                       expected to need more; 192; 288)
+ *   "band_cap"          entries per LDS stage of the band kernel (0 = auto; 192 / 288: float64 and fine-grid kernels;
+ *                       320 / 512: float32 kernel -- the larger one when a lane tile's window is expected to need it)
  *   "kernel"            default yawhip_kernel of yawhip_count_pairs(kernel = AUTO)
  *   "strip_width_micro" spacing, in 1e-6 chord units, of the strip grid of catalogues uploaded afterwards
  *                       (0 = no strips, default 5000). Catalogues counted against each other should share it;
@@ -109,6 +114,9 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *                       orientations are built on first use. 0: the sort axis the catalogues were uploaded with
  *   "slab_budget_bytes" weighted calls keep a slab of partial sums per potential work item; a job list that would need more
  *                       than this many bytes (default 2^30) is counted in pieces, one after the other (same results)
+ *   "band_fp32"         1 (default): on strip layouts of unit vectors the band kernel classifies every evaluation in float32
+ *                       and decides the ones inside a guard band of an edge with the exact float64 predicate (same results);
+ *                       0: every evaluation in float64
  *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every
  *                       2^value stages (default 17: 128 lane objects x 192 entries x 2^17 < 2^32; tests lower it) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
@@ -162,7 +170,8 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
  *   fine_sums    float64[n_jobs][B][E-1] sum of w_a * w_b, a missing weight column counts as 1.0.
  *                No floating point atomics touch global memory: per-item partial sums are combined in a fixed
  *                order. BAND and SWEEP add into a histogram that one wave owns (LDS float64 adds in program
- *                order): bit-reproducible from run to run for a given build and tile_r. EXACT / FILTER keep
+ *                order; adds of ONE instruction that hit the same cell are assumed to be serialised by the LDS in a
+ *                fixed lane order, as observed on MI355X): bit-reproducible from run to run for a given build and tile_r. EXACT / FILTER keep
  *                per-lane private histograms, reduced in a fixed order, while (E-1) * 2 KiB fits LDS (E-1 <= 78);
  *                beyond that they share one LDS histogram between four waves, whose float64 adds are ordered
  *                by the hardware: sums then agree only to rounding (1e-10 relative is what the tests ask)
@@ -171,6 +180,41 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
 int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
                        const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
                        int64_t *fine_counts, double *fine_sums, yawhip_stats *stats);
+
+/*
+ * The same count, returned as the result tensor of PatchLinkage.count_pairs (ABI >= 4; replaces measurements.py:344-364
+ * INCLUDING the host epilogue: the separation weights and per-scale recombination of trees.py:358-362,134-160, the x 0.5
+ * of the diagonal jobs of an autocorrelation, measurements.py:362-363, and the scatter of every job into its slot):
+ *   n_scales        S
+ *   slices          int32[B][S][2]: scale s of bin k sums the fine bins [first, last) of that bin (the indices of the edges
+ *                   nearest to the scale's limits, trees.py:134-160)
+ *   fine_factors    float64[B][E-1] multiplied into the fine bins before they are summed (separation weights,
+ *                   trees.py:358-360), or NULL
+ *   halve_diagonal  non-zero: jobs with equal patch ids count x 0.5 (autocorrelation)
+ *   dense           float64[S][B][P][P], P = the catalogues' patch count; slot [s][k][i][j] of job (i, j), 0 elsewhere
+ * The weighted-sum reproducibility note of yawhip_count_pairs applies; it further assumes that the LDS serialises float64
+ * adds of ONE instruction to the same address in a fixed lane order (observed on MI355X; tested run to run).
+ */
+int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                             const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                             int32_t n_scales, const int32_t *slices, const double *fine_factors, int32_t halve_diagonal,
+                             double *dense, yawhip_stats *stats);
+
+/*
+ * The count of ONE rank of a job list sharded over processes (one process per GPU; ABI >= 4), left on the device for the
+ * final reduce (replaces the result messages of the reference's task farm, src/yaw/utils/parallel.py:251-346):
+ *   jobs, n_jobs    this rank's share
+ *   n_rows_total    jobs of the whole list
+ *   row_index       int32[n_jobs]: position of each of this rank's jobs in the whole list
+ *   device_rows     out: DEVICE pointer to float64[n_rows_total * B * (E-1) + 1], owned by the context and valid until its
+ *                   next call: this rank's rows in place (weighted sums, or the exact conversion of the counts), zero
+ *                   elsewhere -- every row is non-zero on one rank only, so a sum all-reduce (RCCL) over the ranks yields the
+ *                   complete tensor, exactly. The last element is zero: callers use it as a status flag in the reduce.
+ * The context's stream has been waited for when the call returns. Single-device contexts only.
+ */
+int yawhip_count_pairs_rows_device(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                                   const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                                   int64_t n_rows_total, const int32_t *row_index, double **device_rows, yawhip_stats *stats);
 
 /*
  * Nearest patch centre of n objects in Euclidean xyz (replaces scipy.cluster.vq.vq in assign_patch_centers,

@@ -20,6 +20,32 @@ def oracle_count_fine(layout1, layout2, jobs, thresholds, *, kernel=None, sort_a
     return (sums if weighted else counts.astype(np.float64)), CountStats(candidate_pairs=0)
 
 
+def oracle_count_dense(layout1, layout2, jobs, thresholds, slices, fine_factors, halve_diagonal, *, kernel=None, sort_axis=2,
+                       max_workers=None):
+    """Stand-in for yet_another_wizz_amd.engine.count_dense (``yawhip_count_pairs_dense``): the oracle's fine counts, then
+    the host epilogue of ``PatchLinkage.count_pairs`` restated in numpy (separation weights, per-scale sums of the fine
+    bins, x 0.5 on the diagonal jobs of an autocorrelation, scatter into [S, B, P, P])."""
+    fine, stats = oracle_count_fine(layout1, layout2, jobs, thresholds)
+    jobs = np.asarray(jobs).reshape(-1, 2)
+    n_bins, n_scales, n_patches = fine.shape[1], slices.shape[1], layout1.num_patches
+    weighted = fine if fine_factors is None else fine * fine_factors[np.newaxis]
+    factor = np.where(jobs[:, 0] == jobs[:, 1], 0.5, 1.0) if halve_diagonal else 1.0
+    dense = np.zeros((n_scales, n_bins, n_patches, n_patches), dtype=np.float64)
+    for k in range(n_bins):
+        for s in range(n_scales):
+            lo, hi = slices[k, s]
+            dense[s, k, jobs[:, 0], jobs[:, 1]] = weighted[:, k, lo:hi].sum(axis=1) * factor
+    return dense, stats
+
+
+def use_oracle_engine(monkeypatch):
+    """Replace the two seams between the host driver and the HIP library by their oracle stand-ins."""
+    from yet_another_wizz_amd import engine
+
+    monkeypatch.setattr(engine, "count_fine", oracle_count_fine)
+    monkeypatch.setattr(engine, "count_dense", oracle_count_dense)
+
+
 def full_catalogs(tag):
     """The four catalogues of tests/golden/full_<tag>_inputs.npz."""
     import yet_another_wizz_amd as yaw

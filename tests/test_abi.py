@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for name in header_symbols():
         assert hasattr(lib, name), f"libyawhip.so does not export {name}"
     lib.yawhip_abi_version.restype = ctypes.c_int
-    assert lib.yawhip_abi_version() == 3
+    assert lib.yawhip_abi_version() == 4
 
 
 def test_errors_are_reported_not_thrown():

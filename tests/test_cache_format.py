@@ -63,7 +63,7 @@ def test_written_cache_is_format_compatible(tmp_path):
 
 def test_cache_catalog_runs_through_the_driver(monkeypatch):
     """A catalogue restored from a reference cache gives the same counts as one built from the frame."""
-    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.use_oracle_engine(monkeypatch)
     exp = load_golden("refcache_expect.npz")
     frame = dict(ra=exp["input.ra"], dec=exp["input.dec"], z=exp["input.z"], w=exp["input.w"])
     centers = yaw.AngularCoordinates(exp["patch_centers"])
@@ -82,7 +82,7 @@ def test_cache_catalog_runs_through_the_driver(monkeypatch):
 def test_reference_cache_measurements_match_the_reference(monkeypatch):
     """Host logic (oracle standing in for the device): counts measured from the reference-written cache equal what
     the reference measured from it. The device version is tests/test_gpu_api_parity.py::test_reference_cache_on_gpu."""
-    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.use_oracle_engine(monkeypatch)
     helpers.run_refcache_case()
 
 

@@ -83,7 +83,7 @@ def test_random_measurements_device_vs_oracle(seed, monkeypatch):
         return cross, auto
 
     dev_cross, dev_auto = measure()
-    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.use_oracle_engine(monkeypatch)
     ora_cross, ora_auto = measure()
     total = 0.0
     for dev, ora in ((dev_cross, ora_cross), (dev_auto, ora_auto)):

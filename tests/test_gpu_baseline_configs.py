@@ -187,10 +187,10 @@ def test_config4_weighted_autocorrelation_with_10x_randoms(golden):
             d1 = engine.device_catalog(l1, ctx)
             counts, _, _ = _lib.count_pairs(ctx, d1, d1, jobs[jobs[:, 0] == jobs[:, 1]][:8], t, want_counts=True, want_sums=False)
             assert np.all(counts % 2 == 0) and counts.sum() > 0
-    # every count runs on the per-(patch, bin) strip layouts; AUTO takes the band kernel where the streamed runs are
-    # dense (the randoms) and the sweep kernel where they hold a few dozen objects (the data)
+    # every count runs on the per-(patch, bin) strip layouts, on the band kernel (float32 classification: its fixed cost per
+    # item is below the sweep kernel's also where the streamed runs hold a few dozen objects)
     assert modes == {"DD": 3, "DR": 3, "RR": 3}
-    assert kernels["RR"] == _lib.KERNEL_BAND and kernels["DD"] == kernels["DR"] == _lib.KERNEL_SWEEP
+    assert kernels["RR"] == kernels["DD"] == kernels["DR"] == _lib.KERNEL_BAND
     # the public entry point end to end (catalogues resident): Landy-Szalay amplitudes are finite and small
     (cf,) = yaw.autocorrelate(config, data, rand)
     assert cf.dd is not None and cf.dr is not None and cf.rr is not None

@@ -19,17 +19,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo", device_reduce=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), YAW_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
     import torch.distributed as dist
 
     import helpers
     import yet_another_wizz_amd as yaw
+    from yet_another_wizz_amd import measurements
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    measurements.FORCE_DEVICE_REDUCE = device_reduce
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         inp, cats = helpers.full_catalogs("u")
         config = helpers.full_config(inp, "s2", "right")
@@ -50,6 +57,29 @@ def test_three_ranks_share_one_gpu(tmp_path):
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
     results = [np.load(tmp_path / f"ok{r}.npy") for r in range(world)]
     assert all(np.array_equal(results[0], r) for r in results[1:]) and results[0].sum() > 0
+
+
+def test_three_ranks_device_resident_rows(tmp_path):
+    """The device-resident route of the RCCL path (``yawhip_count_pairs_rows_device``: every rank's rows scattered into
+    their place of the full tensor ON the GPU), rehearsed by three gloo ranks on one GPU: the reduce itself then runs on the
+    host, everything before it is the production code."""
+    import torch.multiprocessing as mp
+
+    world = 3
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), "gloo", True), nprocs=world, join=True,
+                       start_method="spawn")
+    results = [np.load(tmp_path / f"ok{r}.npy") for r in range(world)]
+    assert all(np.array_equal(results[0], r) for r in results[1:]) and results[0].sum() > 0
+
+
+def test_one_rank_rccl_reduce_on_the_device(tmp_path):
+    """backend "nccl" (RCCL) with the one GPU this box has: a group of ONE rank takes the several-ranks route -- partition,
+    rows left in HBM, ``torch.as_tensor`` on the library's buffer through ``__cuda_array_interface__``, an RCCL all-reduce
+    on the device, one copy back. (More ranks need more GPUs: the driver's 8-GPU run exercises those.)"""
+    import torch.multiprocessing as mp
+
+    mp.start_processes(_worker, args=(1, _free_port(), str(tmp_path), "nccl", True), nprocs=1, join=True, start_method="spawn")
+    assert np.load(tmp_path / "ok0.npy").sum() > 0
 
 
 def test_multi_device_context_one_call():

@@ -11,7 +11,7 @@ from yet_another_wizz_amd import angular_bins, engine
 
 @pytest.fixture
 def oracle_engine(monkeypatch):
-    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.use_oracle_engine(monkeypatch)
 
 
 @pytest.mark.parametrize("tag", ["u", "w"])

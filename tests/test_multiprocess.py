@@ -77,7 +77,7 @@ def test_process_group_sharding_matches_single_process(tmp_path, monkeypatch, wo
     from yet_another_wizz_amd import engine
 
     mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="spawn")
-    monkeypatch.setattr(engine, "count_fine", helpers.oracle_count_fine)
+    helpers.use_oracle_engine(monkeypatch)
     inp, cats = helpers.full_catalogs("w")
     config = helpers.full_config(inp, "s2", "right")
     cfs = yaw.crosscorrelate(config, cats["ref"], cats["unk"], ref_rand=cats["ref_rand"], unk_rand=cats["unk_rand"])

@@ -36,6 +36,8 @@ ABI_SYMBOLS = (
     "yawhip_catalog_free",
     "yawhip_catalog_device_bytes",
     "yawhip_count_pairs",
+    "yawhip_count_pairs_dense",
+    "yawhip_count_pairs_rows_device",
     "yawhip_job_work",
     "yawhip_assign_patches",
     "yawhip_host_group_columns",
@@ -60,6 +62,9 @@ class _Stats(ctypes.Structure):
         ("count_ms", ctypes.c_double),
         ("layout_mode", ctypes.c_int32),
         ("n_orientations", ctypes.c_int32),
+        ("exact_reevaluations", ctypes.c_int64),
+        ("band_variant", ctypes.c_int32),
+        ("reserved_", ctypes.c_int32),
     ]
 
 
@@ -76,6 +81,9 @@ class CountStats:
     count_ms: float = 0.0
     layout_mode: int = 0
     n_orientations: int = 0
+    exact_reevaluations: int = 0
+    band_variant: int = 0
+    reserved_: int = 0
 
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -121,6 +129,14 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_count_pairs.argtypes = [
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
         _i64p, _dp, ctypes.POINTER(_Stats),
+    ]
+    lib.yawhip_count_pairs_dense.argtypes = [
+        _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
+        ctypes.c_int32, _i32p, _dp, ctypes.c_int32, _dp, ctypes.POINTER(_Stats),
+    ]
+    lib.yawhip_count_pairs_rows_device.argtypes = [
+        _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
+        ctypes.c_int64, _i32p, ctypes.POINTER(_vp), ctypes.POINTER(_Stats),
     ]
     lib.yawhip_assign_patches.argtypes = [_vp, ctypes.c_int64, _dp, _dp, _dp, ctypes.c_int32, _dp, _i32p]
     lib.yawhip_job_work.argtypes = [
@@ -272,6 +288,58 @@ def count_pairs(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresh
     )
     stats = CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
     return counts, sums, stats
+
+
+def count_pairs_dense(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresholds, slices, fine_factors, halve_diagonal,
+                      *, kernel="auto"):
+    """Run ``yawhip_count_pairs_dense``: the result tensor f64[S, B, P, P] of ``PatchLinkage.count_pairs`` in one call.
+
+    jobs: int32[n_jobs, 2] (C contiguous); thresholds: f64[B, E]; slices: int32[B, S, 2]; fine_factors: f64[B, E-1] | None."""
+    n_bins, n_edges = thresholds.shape
+    n_scales = slices.shape[1]
+    dense = np.empty((n_scales, n_bins, c1.n_patches, c1.n_patches), dtype=np.float64)  # the library writes every element
+    st = _Stats()
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    _check(
+        load_library().yawhip_count_pairs_dense(
+            ctx._h, c1._h, c2._h, len(jobs), _ptr(jobs, _i32p), n_bins, n_edges, _ptr(thresholds, _dp), kid,
+            n_scales, _ptr(slices, _i32p), _ptr(fine_factors, _dp), 1 if halve_diagonal else 0, _ptr(dense, _dp), ctypes.byref(st),
+        ),
+        "yawhip_count_pairs_dense",
+    )
+    return dense, CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
+
+
+class DeviceRows:
+    """float64[n] in the HBM of ``device``, owned by a context (valid until its next call); exposes
+    ``__cuda_array_interface__`` so that torch wraps it without a copy (``torch.as_tensor(rows, device=...)``)."""
+
+    def __init__(self, ptr: int, n: int, device: int):
+        self.ptr, self.n, self.device = int(ptr), int(n), int(device)
+        self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "<f8", "data": (self.ptr, False), "version": 3,
+                                         "strides": None}
+
+
+def count_pairs_rows_device(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresholds, n_rows_total: int, row_index,
+                            *, kernel="auto"):
+    """Run ``yawhip_count_pairs_rows_device``: this rank's rows of a sharded count, in place in the full tensor, left on
+    the device. Returns (DeviceRows of n_rows_total * B * (E-1) + 1 values, CountStats)."""
+    jobs = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2)
+    t = np.ascontiguousarray(thresholds, dtype=np.float64)
+    row_index = np.ascontiguousarray(row_index, dtype=np.int32)
+    n_bins, n_edges = t.shape
+    st = _Stats()
+    out = _vp()
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    _check(
+        load_library().yawhip_count_pairs_rows_device(
+            ctx._h, c1._h, c2._h, len(jobs), _ptr(jobs, _i32p), n_bins, n_edges, _ptr(t, _dp), kid,
+            int(n_rows_total), _ptr(row_index, _i32p), ctypes.byref(out), ctypes.byref(st),
+        ),
+        "yawhip_count_pairs_rows_device",
+    )
+    n = int(n_rows_total) * n_bins * (n_edges - 1) + 1
+    return DeviceRows(out.value, n, ctx.device), CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
 
 
 def job_work(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, thresholds, *, kernel="auto") -> np.ndarray:

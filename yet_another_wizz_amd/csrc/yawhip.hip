@@ -1412,7 +1412,8 @@ __host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots,
 // The exact predicate of the parity contract on the float64 columns, for an evaluation the float32 classes left undecided
 // (rare: kept out of line so that its addresses and temporaries do not live in the walk loop's registers).
 __device__ __attribute__((noinline)) double band32_exact_s(gf64p lx, gf64p ly, gf64p lz, int64_t li, gf64p sx, gf64p sy, gf64p sz,
-                                                           int64_t gi) {
+                                                           int64_t gi, unsigned long long *__restrict__ counters) {
+    atomicAdd(&counters[2], 1ull);  // statistics: evaluations decided by the exact predicate
     const double dx = lx[li] - sx[gi], dy = ly[li] - sy[gi], dz = lz[li] - sz[gi];
     const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
     const double sxy = xx + yy;
@@ -1748,7 +1749,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx);
+                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx, counters);
                             const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
                             if constexpr (NE == 2) {
                                 const bool in = sd > tk[0] && sd <= tk[1];
@@ -2015,7 +2016,7 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                             if (!(s32[r] < tm) && !(s32[r] > tp)) {  // inside the guard band of edge j
                                 bin = -1;
                                 if (eidx < (unsigned)n && r < n_own) {
-                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx);
+                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx, counters);
                                     const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * n_edges;
                                     bin = sd <= tk[j] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
                                     if (bin >= 0 && !(sd > tk[bin])) bin = -1;        // (degenerate tables: equal edges)
@@ -2096,6 +2097,15 @@ __global__ void k_reduce_slots(const double *__restrict__ chunk_sums, const int6
     double acc = 0.0;
     for (int64_t g = cprefix[slot]; g < cprefix[slot + 1]; ++g) acc += chunk_sums[g * slab + e];
     out[idx] = acc;
+}
+
+// rows of a call's result into their place in the full [rows][row] tensor (device-resident all-reduce of the process route)
+__global__ void k_scatter_rows(const double *__restrict__ in, const int32_t *__restrict__ row_index, int64_t row, int64_t n,
+                               double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / row;
+    out[(int64_t)row_index[r] * row + (i - r * row)] = in[i];
 }
 
 __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, double *__restrict__ out, int64_t n) {
@@ -2199,6 +2209,8 @@ struct yawhip_ctx {
     DevBuf<int64_t> d_cprefix;
     DevBuf<unsigned char> d_kept;   // weighted runs: 1 for potential items the builder kept
     DevBuf<unsigned long long> d_jobwork;
+    DevBuf<double> d_full;          // yawhip_count_pairs_rows_device: the full result tensor of a sharded count
+    DevBuf<int32_t> d_rowidx;
     Arena in, out;  // per-call tables (host -> device) and results (device -> host)
     View<DevTab> d_tabs;
     // A context made by yawhip_ctx_create_multi owns one further context per additional device: catalogues are
@@ -2709,6 +2721,8 @@ int yawhip_ctx_destroy(yawhip_ctx *ctx) {
     ctx->d_cprefix.release();
     ctx->d_kept.release();
     ctx->d_jobwork.release();
+    ctx->d_full.release();
+    ctx->d_rowidx.release();
     ctx->in.release();
     ctx->out.release();
     ctx->sort_ws.release();
@@ -2968,7 +2982,7 @@ struct CallState {
     size_t o_ctr = 0, o_counts = 0, o_sums = 0;
     bool want_counts = false, want_sums = false, band_ran = false, run_unweighted = false, run_weighted = false;
     int64_t cand = 0, abytes = 0, n_pot = 0;
-    int launches = 0, kernel = 0, mode = 0, n_orient = 0;
+    int launches = 0, kernel = 0, mode = 0, n_orient = 0, band_variant = 0;
 };
 
 // Float32 bounds of every edge for k_count_band32 (see there): for unit vectors rounded to float32,
@@ -3179,13 +3193,16 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const yawhip_catalog *c_lane = swap ? c1 : c2, *c_strm = swap ? c2 : c1;
     const StripLayout *const *LL = swap ? L1 : L2, *const *LS = swap ? L2 : L1;  // lane side, streamed side
     if (auto_pick && band && unit) {
-        // The band kernel decides every entry of a per-object band in FP64: unbeatable while a band is a handful of
-        // entries of which half are pairs (strip layouts of dense catalogues). Without strips a band is the whole
-        // u-window of a segment, nearly all of it far away along v -- the FP32 pre-filter of the sweep kernel is made
-        // for that; and when the streamed runs hold a few dozen objects (sparse data against dense randoms) a work item
-        // is all fixed cost, which the sweep kernel has less of (measured on config #4).
+        // The band kernel decides every entry of a per-object band: unbeatable while a band is a handful of entries of which
+        // half are pairs (strip layouts). Without strips a band is the whole u-window of a segment, nearly all of it far away
+        // along v -- the FP32 pre-filter of the sweep kernel is made for that. Sparse streamed runs (a few dozen objects: an
+        // item is all fixed cost) went to the sweep kernel while the band kernel evaluated in float64; the float32 band kernel
+        // has the smaller fixed cost (measured: DD of config #4 0.61 against 0.83 ms, 1M x 1M / 64 patches 0.047 against 0.102,
+        // 3M x 0.3M 0.09 against 0.28; sweep stays ahead only where the two sides differ tenfold in density and the items are
+        // tiny: DR of config #4 2.09 against 2.23 ms, 0.3M x 3M 0.092 against 0.119) -- so only the float64 band kernel
+        // (band_fp32 = 0, more than four edges off the log grid) keeps the density rule.
         bool use_sweep = mode == 0;
-        if (!use_sweep) {
+        if (!use_sweep && !want32 && !want_fine) {
             double obj_run = 0.0;  // of the densest built orientation
             for (int o = 0; o < 3; ++o)
                 if (LS[o]) obj_run = std::max(obj_run, LS[o]->obj_run);
@@ -3762,22 +3779,43 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     cs.cand = cand; cs.abytes = abytes; cs.n_pot = n_pot;
     cs.launches = launches; cs.kernel = kernel; cs.mode = mode;
     cs.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
+    cs.band_variant = !band_ran ? 0 : (band32 ? 32 : (band_fine ? 33 : 64));
     return YAWHIP_OK;
 }
 
 // Second half: wait for the context's stream, hand the results (contiguous rows of the jobs given to count_enqueue) and
 // the statistics over.
-int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, double *fine_sums, yawhip_stats *stats) {
+// row_index != nullptr: row r of this call's result goes to row row_index[r] of the caller's arrays (rows of row_len values):
+// the devices of a multi-device call write their shares straight into place.
+int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, double *fine_sums, yawhip_stats *stats,
+                 const int32_t *row_index = nullptr, int64_t row_len = 0) {
     if (stats) memset(stats, 0, sizeof *stats);
+    const int64_t n_rows = row_index && row_len > 0 ? cs.n_out / row_len : 0;
     if (!cs.pending) {
-        if (fine_counts) memset(fine_counts, 0, sizeof(int64_t) * (size_t)cs.n_out);
-        if (fine_sums) memset(fine_sums, 0, sizeof(double) * (size_t)cs.n_out);
+        if (!row_index) {
+            if (fine_counts) memset(fine_counts, 0, sizeof(int64_t) * (size_t)cs.n_out);
+            if (fine_sums) memset(fine_sums, 0, sizeof(double) * (size_t)cs.n_out);
+        } else {
+            for (int64_t r = 0; r < n_rows; ++r) {
+                if (fine_counts) memset(fine_counts + (size_t)row_index[r] * row_len, 0, sizeof(int64_t) * (size_t)row_len);
+                if (fine_sums) memset(fine_sums + (size_t)row_index[r] * row_len, 0, sizeof(double) * (size_t)row_len);
+            }
+        }
         return YAWHIP_OK;
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (fine_counts) memcpy(fine_counts, ctx->out.h + cs.o_counts, sizeof(int64_t) * (size_t)cs.n_out);
-    if (fine_sums) memcpy(fine_sums, ctx->out.h + cs.o_sums, sizeof(double) * (size_t)cs.n_out);
+    if (!row_index) {
+        if (fine_counts) memcpy(fine_counts, ctx->out.h + cs.o_counts, sizeof(int64_t) * (size_t)cs.n_out);
+        if (fine_sums) memcpy(fine_sums, ctx->out.h + cs.o_sums, sizeof(double) * (size_t)cs.n_out);
+    } else {
+        const int64_t *hc = reinterpret_cast<const int64_t *>(ctx->out.h + cs.o_counts);
+        const double *hs = reinterpret_cast<const double *>(ctx->out.h + cs.o_sums);
+        for (int64_t r = 0; r < n_rows; ++r) {
+            if (fine_counts) memcpy(fine_counts + (size_t)row_index[r] * row_len, hc + (size_t)r * row_len, sizeof(int64_t) * (size_t)row_len);
+            if (fine_sums) memcpy(fine_sums + (size_t)row_index[r] * row_len, hs + (size_t)r * row_len, sizeof(double) * (size_t)row_len);
+        }
+    }
     const unsigned long long *ctr = reinterpret_cast<const unsigned long long *>(ctx->out.h + cs.o_ctr);
     if (stats) {
         float ms = 0.f;
@@ -3798,6 +3836,8 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         stats->kernel_used = cs.kernel;
         stats->layout_mode = cs.mode;
         stats->n_orientations = cs.n_orient;
+        stats->band_variant = cs.band_variant;
+        stats->exact_reevaluations = cs.band_ran ? (int64_t)ctr[2] : 0;
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cs.wall0).count();
     }
@@ -3813,6 +3853,8 @@ void add_stats(yawhip_stats &total, const yawhip_stats &part, bool side_by_side)
     total.kernel_used = part.kernel_used;
     total.layout_mode = part.layout_mode;
     total.n_orientations = std::max(total.n_orientations, part.n_orientations);
+    total.band_variant = part.band_variant;
+    total.exact_reevaluations += part.exact_reevaluations;
     if (side_by_side) {  // devices of one call run at the same time: the slowest counts
         total.kernel_ms = std::max(total.kernel_ms, part.kernel_ms);
         total.count_ms = std::max(total.count_ms, part.count_ms);
@@ -3981,27 +4023,153 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
     std::vector<double> rows_s;
     yawhip_stats total{}, part{};
     int rc_all = YAWHIP_OK;
-    for (size_t d = 0; d < n_dev; ++d) {
+    for (size_t d = 0; d < n_dev; ++d) {  // every device's copy into its pinned buffer is already under way: drain in turn
         yawhip_ctx *dc = d == 0 ? ctx : ctx->peers[d - 1];
         const yawhip_catalog *a = d == 0 ? c1 : c1->replicas[d - 1], *b = d == 0 ? c2 : c2->replicas[d - 1];
         const size_t nj = ctx->plan.parts[d].size();
-        if (fine_counts) rows_c.resize(nj * (size_t)row);
-        if (fine_sums) rows_s.resize(nj * (size_t)row);
-        const int rc = later[d] ? run_single(dc, a, b, (int32_t)nj, sub[d].data(), n_bins, n_edges, t, kernel,
-                                             fine_counts ? rows_c.data() : nullptr, fine_sums ? rows_s.data() : nullptr, &part)
-                                : count_finish(dc, states[d], fine_counts ? rows_c.data() : nullptr,
-                                               fine_sums ? rows_s.data() : nullptr, &part);
-        if (rc != YAWHIP_OK) { rc_all = rc; continue; }  // keep draining the other devices
-        for (size_t r = 0; r < nj; ++r) {
-            const size_t j = (size_t)ctx->plan.parts[d][r];
-            if (fine_counts) memcpy(fine_counts + j * (size_t)row, rows_c.data() + r * (size_t)row, sizeof(int64_t) * (size_t)row);
-            if (fine_sums) memcpy(fine_sums + j * (size_t)row, rows_s.data() + r * (size_t)row, sizeof(double) * (size_t)row);
+        int rc;
+        if (later[d]) {  // a share that is counted in pieces: through a temporary, then into place
+            if (fine_counts) rows_c.resize(nj * (size_t)row);
+            if (fine_sums) rows_s.resize(nj * (size_t)row);
+            rc = run_single(dc, a, b, (int32_t)nj, sub[d].data(), n_bins, n_edges, t, kernel, fine_counts ? rows_c.data() : nullptr,
+                            fine_sums ? rows_s.data() : nullptr, &part);
+            if (rc == YAWHIP_OK)
+                for (size_t r = 0; r < nj; ++r) {
+                    const size_t j = (size_t)ctx->plan.parts[d][r];
+                    if (fine_counts) memcpy(fine_counts + j * (size_t)row, rows_c.data() + r * (size_t)row, sizeof(int64_t) * (size_t)row);
+                    if (fine_sums) memcpy(fine_sums + j * (size_t)row, rows_s.data() + r * (size_t)row, sizeof(double) * (size_t)row);
+                }
+        } else {         // rows go from the device's pinned buffer straight into the caller's arrays
+            rc = count_finish(dc, states[d], fine_counts, fine_sums, &part, ctx->plan.parts[d].data(), row);
         }
+        if (rc != YAWHIP_OK) { rc_all = rc; continue; }  // keep draining the other devices
         add_stats(total, part, true);
     }
     if (rc_all != YAWHIP_OK) return rc_all;
     total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = total;
+    return YAWHIP_OK;
+}
+
+int yawhip_count_pairs_rows_device(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                                   const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                                   int64_t n_rows_total, const int32_t *row_index, double **device_rows, yawhip_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!ctx || !c1 || !c2 || !device_rows) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_rows_device: NULL argument");
+    *device_rows = nullptr;
+    if (!ctx->peers.empty()) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_rows_device: single-device contexts only");
+    if (n_jobs < 0 || n_rows_total < n_jobs || n_bins <= 0 || n_edges < 2 || (n_jobs > 0 && (!jobs || !row_index)))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_rows_device: bad sizes or NULL arrays");
+    const int64_t row = (int64_t)n_bins * (n_edges - 1);
+    for (int j = 0; j < n_jobs; ++j)
+        if (row_index[j] < 0 || row_index[j] >= n_rows_total)
+            return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_rows_device: row index %d outside [0, %lld)", row_index[j], (long long)n_rows_total);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n_full = (size_t)n_rows_total * (size_t)row + 1;  // + 1: the caller's status element
+    HIP_TRY(ctx->d_full.reserve(n_full));
+    HIP_TRY(ctx->d_rowidx.reserve((size_t)std::max(n_jobs, 1)));
+    CallState cs;
+    int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, false, true, nullptr, cs);
+    if (rc == SPLIT_JOBS) {
+        // a job list that is counted in pieces: through the host (rare: weighted slabs beyond the budget)
+        std::vector<double> rows((size_t)n_jobs * (size_t)row), full(n_full, 0.0);
+        rc = run_single(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, nullptr, rows.data(), stats);
+        if (rc != YAWHIP_OK) return rc;
+        for (int j = 0; j < n_jobs; ++j)
+            memcpy(full.data() + (size_t)row_index[j] * row, rows.data() + (size_t)j * row, sizeof(double) * (size_t)row);
+        HIP_TRY(hipMemcpy(ctx->d_full.ptr, full.data(), sizeof(double) * n_full, hipMemcpyHostToDevice));
+        *device_rows = ctx->d_full.ptr;
+        return YAWHIP_OK;
+    }
+    if (rc != YAWHIP_OK) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->d_full.ptr, 0, sizeof(double) * n_full, ctx->stream));
+    if (cs.pending && n_jobs > 0) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_rowidx.ptr, row_index, sizeof(int32_t) * (size_t)n_jobs, hipMemcpyHostToDevice, ctx->stream));
+        const int64_t n = (int64_t)n_jobs * row;
+        hipLaunchKernelGGL(k_scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_sums.ptr,
+                           ctx->d_rowidx.ptr, row, n, ctx->d_full.ptr);
+        HIP_TRY(hipGetLastError());
+    }
+    rc = count_finish(ctx, cs, nullptr, nullptr, stats);  // waits for the stream: the rows are in place when this returns
+    if (rc != YAWHIP_OK) return rc;
+    *device_rows = ctx->d_full.ptr;
+    return YAWHIP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// ndarray.sum() of a contiguous float64 vector, in numpy's order (pairwise summation: plain loop below 8 values, eight
+// running sums up to 128, halves above): the reference sums the fine bins of a scale this way (trees.py:134-160), so
+// separation-weighted counts of unweighted catalogues come out bit for bit as the reference's.
+double numpy_sum(const double *a, int64_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_sum(a, n2) + numpy_sum(a + n2, n - n2);
+}
+}  // namespace
+
+extern "C" {
+
+int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs,
+                             const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
+                             int32_t n_scales, const int32_t *slices, const double *fine_factors, int32_t halve_diagonal,
+                             double *dense, yawhip_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_dense: NULL handle");
+    if (n_jobs < 0 || n_bins <= 0 || n_edges < 2 || n_scales <= 0 || !slices || !dense || (n_jobs > 0 && !jobs))
+        return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_dense: bad sizes or NULL arrays");
+    const int nf = n_edges - 1;
+    for (int64_t i = 0; i < (int64_t)n_bins * n_scales; ++i)
+        if (slices[2 * i] < 0 || slices[2 * i + 1] > nf)
+            return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_dense: slice %lld outside [0, %d]", (long long)i, nf);
+    const int64_t P = c1->n_patches, row = (int64_t)n_bins * nf;
+    std::vector<double> fine;
+    try {
+        fine.resize((size_t)std::max<int64_t>((int64_t)n_jobs * row, 1));
+    } catch (const std::bad_alloc &) {
+        return fail(YAWHIP_ERR_OOM, "yawhip_count_pairs_dense: out of host memory");
+    }
+    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, nullptr, fine.data(), stats);
+    if (rc != YAWHIP_OK) return rc;
+    // Host epilogue, O(jobs x B x E), of PatchLinkage.count_pairs (reference src/yaw/correlation/measurements.py:354-364 with
+    // src/yaw/catalog/trees.py:358-362,134-160 applied per job): separation weights, per-scale sums of the fine bins, halving
+    // of the doubly counted diagonal of an autocorrelation, scatter into [scale][bin][patch i][patch j]; unlinked slots are 0.
+    memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
+    std::vector<double> scaled((size_t)nf);
+    for (int64_t j = 0; j < n_jobs; ++j) {
+        const int64_t p = jobs[2 * j], q = jobs[2 * j + 1];
+        if (p < 0 || p >= P || q < 0 || q >= P) return fail(YAWHIP_ERR_INVALID, "job %lld has a patch id outside [0,%lld)", (long long)j, (long long)P);
+        const double f = (halve_diagonal && p == q) ? 0.5 : 1.0;
+        for (int k = 0; k < n_bins; ++k) {
+            const double *fk = fine.data() + (size_t)j * row + (size_t)k * nf;
+            if (fine_factors) {  // counts *= weights (trees.py:358-360), then the sums
+                const double *wk = fine_factors + (size_t)k * nf;
+                for (int e = 0; e < nf; ++e) scaled[(size_t)e] = fk[e] * wk[e];
+                fk = scaled.data();
+            }
+            for (int s_ = 0; s_ < n_scales; ++s_) {
+                const int lo = slices[2 * ((int64_t)k * n_scales + s_)], hi = slices[2 * ((int64_t)k * n_scales + s_) + 1];
+                const double acc = hi > lo ? numpy_sum(fk + lo, hi - lo) : 0.0;
+                dense[(((size_t)s_ * n_bins + k) * P + p) * P + q] = acc * f;
+            }
+        }
+    }
     return YAWHIP_OK;
 }
 

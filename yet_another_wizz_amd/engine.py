@@ -14,7 +14,7 @@ import os
 from . import _lib
 from .parallel import local_device_index, world
 
-__all__ = ["get_context", "device_catalog", "count_fine", "job_work", "assign_patches", "release", "default_kernel"]
+__all__ = ["get_context", "device_catalog", "count_fine", "count_dense", "job_work", "assign_patches", "release", "default_kernel"]
 
 _contexts: dict = {}
 default_kernel = "auto"
@@ -111,6 +111,24 @@ def count_fine(layout1, layout2, jobs, thresholds, *, kernel: str | None = None,
     counts, sums, stats = _lib.count_pairs(ctx, d1, d2, jobs, thresholds, kernel=kernel or default_kernel)
     fine = sums if sums is not None else counts.astype(np.float64)
     return fine, stats
+
+
+def count_dense(layout1, layout2, jobs, thresholds, slices, fine_factors, halve_diagonal, *, kernel: str | None = None,
+                sort_axis: int = 2, max_workers: int | None = None):
+    """The result tensor f64[S, B, P, P] of one pair count from ONE library call (``yawhip_count_pairs_dense``) and its
+    ``CountStats``; ``slices`` / ``fine_factors`` describe the per-scale recombination (``CombinePlan.dense_spec``)."""
+    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis, max_workers)
+    return _lib.count_pairs_dense(ctx, d1, d2, np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2),
+                                  np.ascontiguousarray(thresholds, dtype=np.float64), slices, fine_factors, halve_diagonal,
+                                  kernel=kernel or default_kernel)
+
+
+def count_rows_device(layout1, layout2, jobs, thresholds, n_rows_total: int, row_index, *, kernel: str | None = None,
+                      sort_axis: int = 2):
+    """This rank's share of a sharded count, left on the device in its place of the full [jobs, B, E-1] tensor
+    (``yawhip_count_pairs_rows_device``) -> (``_lib.DeviceRows``, CountStats)."""
+    ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis)
+    return _lib.count_pairs_rows_device(ctx, d1, d2, jobs, thresholds, n_rows_total, row_index, kernel=kernel or default_kernel)
 
 
 def _device_pair(layout1, layout2, thresholds, sort_axis, max_workers=None):

@@ -86,6 +86,18 @@ class CombinePlan:
         # the common case: one scale made of the one fine bin the device counted
         self.single = self.uniform and self.scale_factors is None and self.slices == [(0, 1)] and self.num_fine == 1
 
+    def dense_spec(self, num_fine: int):
+        """The recombination as ``yawhip_count_pairs_dense`` takes it: ``slices`` int32[B, S, 2] (fine bins [first, last)
+        of every scale and bin) and ``factors`` f64[B, num_fine] (separation weights, 0 for the padded fine bins of a bin
+        with fewer edges) or None."""
+        slices = np.ascontiguousarray([p._slices for p in self.plans], dtype=np.int32)
+        factors = None
+        if any(p._scale_factor is not None for p in self.plans):
+            factors = np.zeros((len(self.plans), num_fine), dtype=np.float64)
+            for k, p in enumerate(self.plans):
+                factors[k, : p.num_edges - 1] = 1.0 if p._scale_factor is None else p._scale_factor
+        return slices, factors
+
     def __call__(self, fine_bej) -> np.ndarray:
         if self.single:
             return fine_bej[:, 0][np.newaxis]  # a view: [1, B, J]
@@ -118,6 +130,8 @@ def threshold_table(plans) -> np.ndarray:
         table[k, plan.num_edges :] = plan.thresholds[-1]
     return table
 
+
+FORCE_DEVICE_REDUCE = False  # tests: take the device-resident reduce of the nccl route in any group
 
 JOB_FIXED_COST = 2.0e5  # evaluated-pair equivalent of touching a job at all (launch share, empty windows)
 
@@ -184,6 +198,7 @@ class PatchLinkage:
         self._job_tables: dict = {}
         self._scatter: dict = {}
         self._partitions: dict = {}
+        self._dense_spec = None
 
     def _angular_setup(self):
         if self._plans is None:
@@ -275,45 +290,70 @@ class PatchLinkage:
         # per GPU under torch.distributed: the jobs are sharded over the ranks here and one sum all-reduce combines
         # the result (every slot is non-zero on exactly one rank: the sum is exact and order independent).
         rank, size = parallel.world()
-        mine = None  # every job
-        if size > 1:
-            # balance what the device will really evaluate (lane tile x window sizes, from the item builder); the
-            # partition is a plan: rank 0 derives it once per (catalogue pair, group size) and broadcasts it
-            key = (id(layout1), id(layout2), len(layout1.x), len(layout2.x), len(jobs), auto, size)
+        if size == 1 and not FORCE_DEVICE_REDUCE:
+            # one process: the library returns the result tensor [S, B, P, P] from ONE call (yawhip_count_pairs_dense:
+            # counting on the GPU(s), then separation weights, per-scale sums, the x 0.5 of an autocorrelation's diagonal
+            # jobs and the scatter into the slots in C)
+            if self._dense_spec is None:
+                self._dense_spec = self._combine.dense_spec(num_fine)
+            slices, factors = self._dense_spec
+            counts, stats = engine.count_dense(layout1, layout2, jobs, thresholds, slices, factors, auto,
+                                               sort_axis=self.sort_axis, max_workers=max_workers)
+            self.last_stats = stats
+            self._report(count_type_info, len(jobs), stats, progress)
+            scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(counts.shape[0])]
+            sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
+                                            auto=auto)
+            return [NormalisedCounts(c, sum_weights) for c in scale_counts]
+        # Several ranks: balance what the device will really evaluate (lane tile x window sizes, from the item builder); the
+        # partition is a plan: rank 0 derives it once per (catalogue pair, group size) and broadcasts it
+        # (rank-independent key: every rank enters the broadcast below, or none does)
+        key = (len(layout1.x), len(layout2.x), layout1.num_bins, layout2.num_bins, len(jobs), auto, size)
+        if True:
             if key not in self._partitions:
                 parts = None
                 if rank == 0:
-                    work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
-                    parts = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
-                self._partitions[key] = parallel.broadcast_object(parts)
+                    try:
+                        work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
+                        parts = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
+                    except Exception as err:  # noqa: BLE001 -- the other ranks wait in the broadcast: tell them
+                        parts = err
+                parts = parallel.broadcast_object(parts)
+                if isinstance(parts, Exception):
+                    raise RuntimeError(f"the job partition could not be derived on rank 0: {parts}") from parts
+                self._partitions[key] = parts
             mine = self._partitions[key][rank]
-        failure = None
+        failure, fine, rows = None, None, None
+        n_compact = len(jobs) * num_bins * num_fine + 1
+        on_device = parallel.device_collectives() or FORCE_DEVICE_REDUCE
         try:
-            fine, stats = engine.count_fine(layout1, layout2, jobs if mine is None else jobs[mine], thresholds,
-                                            sort_axis=self.sort_axis, max_workers=max_workers)
+            if on_device:  # this rank's rows stay in HBM, in their place of the full tensor (zero elsewhere)
+                rows, stats = engine.count_rows_device(layout1, layout2, jobs[mine], thresholds, len(jobs), mine,
+                                                       sort_axis=self.sort_axis)
+            else:
+                fine, stats = engine.count_fine(layout1, layout2, jobs[mine], thresholds, sort_axis=self.sort_axis,
+                                                max_workers=max_workers)
             self.last_stats = stats
         except Exception as err:  # noqa: BLE001 -- with several ranks the others must not wait for this one forever
-            if size == 1:
-                raise
-            failure, fine = err, None
+            failure = err
 
         id1, id2 = jobs[:, 0], jobs[:, 1]
-        if size > 1:
-            # only linked patch pairs carry counts: the tensor travels in its compact [jobs, B, E-1] form (every rank
-            # holds the same job table), 9x smaller than the dense [B, E-1, P, P] at 64 patches; one extra element
-            # carries the number of ranks that failed, so that all of them raise instead of one leaving the rest
-            # blocked in the collective
-            compact = np.zeros(len(jobs) * num_bins * num_fine + 1, dtype=np.float64)
+        # only linked patch pairs carry counts: the tensor travels in its compact [jobs, B, E-1] form (every rank holds
+        # the same job table), 9x smaller than the dense [B, E-1, P, P] at 64 patches; every row is non-zero on exactly
+        # one rank, so ONE sum all-reduce (RCCL over xGMI) yields the complete tensor, exactly; one extra element carries
+        # the number of ranks that failed, so that all of them raise instead of one leaving the rest blocked in the collective
+        if on_device:
+            compact = parallel.allreduce_device_rows(rows, n_compact, status=1.0 if failure is not None else 0.0)
+        else:
+            compact = np.zeros(n_compact, dtype=np.float64)
             if failure is not None:
                 compact[-1] = 1.0
             elif len(mine):
                 compact[:-1].reshape(len(jobs), num_bins, num_fine)[mine] = fine
             compact = parallel.allreduce_sum(compact)
-            if compact[-1] > 0:
-                raise RuntimeError(f"pair counting failed on {int(compact[-1])} of {size} ranks") from failure
-            fine_bej = np.moveaxis(compact[:-1].reshape(len(jobs), num_bins, num_fine), 0, -1)
-        else:
-            fine_bej = np.moveaxis(fine, 0, -1)
+        if compact[-1] > 0:
+            raise RuntimeError(f"pair counting failed on {int(compact[-1])} of {size} ranks") from failure
+        fine_bej = np.moveaxis(compact[:-1].reshape(len(jobs), num_bins, num_fine), 0, -1)
 
         # host epilogue, O(jobs * B * E): separation weights, per-scale recombination, halving of the doubly
         # counted diagonal of an autocorrelation (trees.py:358-362, measurements.py:361-364), scatter into [B, P, P]
@@ -331,7 +371,21 @@ class PatchLinkage:
 
         sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins),
                                         auto=auto)
+        if failure is None and self.last_stats is not None:
+            self._report(count_type_info, len(jobs), self.last_stats, progress)
         return [NormalisedCounts(counts, sum_weights) for counts in scale_counts]
+
+    @staticmethod
+    def _report(what, n_jobs, stats, progress) -> None:
+        """The reference logs every pair count and shows a progress bar over its patch-pair tasks
+        (src/yaw/correlation/measurements.py:53-62,344-350); one GPU call has no tasks to tick off, so ``progress`` prints
+        one summary line per count instead. Rank 0 only."""
+        secs = max(stats.total_ms, 1e-6) / 1e3
+        line = (f"{what or 'pair count'}: {n_jobs} patch pairs, {stats.candidate_pairs:.4g} candidate pairs in "
+                f"{stats.total_ms:.2f} ms ({stats.candidate_pairs / secs:.3g} pairs/s)")
+        _log_info(line)
+        if progress and parallel.world()[0] == 0:
+            print(line, flush=True)
 
     def count_pairs_optional(self, main_catalog, *optional_catalog, **kwargs):
         """``count_pairs`` that yields ``None`` per scale if any catalogue is missing

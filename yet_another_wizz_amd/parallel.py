@@ -12,7 +12,8 @@ import os
 
 import numpy as np
 
-__all__ = ["world", "partition_jobs", "allreduce_sum", "broadcast_object", "local_device_index"]
+__all__ = ["world", "partition_jobs", "allreduce_sum", "allreduce_device_rows", "device_collectives", "broadcast_object",
+           "local_device_index"]
 
 
 def _dist():
@@ -64,6 +65,33 @@ def allreduce_sum(array: np.ndarray) -> np.ndarray:
     return tensor.cpu().numpy()
 
 
+def device_collectives() -> bool:
+    """True when the process group reduces device memory directly (backend "nccl" = RCCL over xGMI)."""
+    dist = _dist()
+    return dist is not None and dist.get_backend() == "nccl"
+
+
+def allreduce_device_rows(rows, n: int, status: float = 0.0) -> np.ndarray:
+    """Sum all-reduce of a float64[n] tensor that already lives on this rank's GPU (``_lib.DeviceRows``: the library's
+    result buffer, wrapped by torch without a copy) -- or, for a rank that has nothing to contribute (``rows`` None), of
+    zeros. ``status`` is added to the last element (the failure flag of ``PatchLinkage.count_pairs``). One device-to-host
+    copy brings the reduced tensor back."""
+    import torch
+
+    dist = _dist()
+    device = torch.device("cuda", local_device_index())
+    tensor = torch.zeros(n, dtype=torch.float64, device=device) if rows is None else torch.as_tensor(rows, device=device)
+    if status:
+        tensor[-1] += status
+    if dist is not None and dist.get_backend() == "nccl":
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL, on the device
+        return tensor.cpu().numpy()
+    host = tensor.cpu()  # rehearsals on another backend (several ranks sharing one GPU under gloo): reduce on the host
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    return host.numpy()
+
+
 def broadcast_object(obj, src: int = 0):
     """``obj`` of rank ``src`` on every rank (a plan such as the job partition: small, sent once); identity for a
     single process."""
@@ -71,5 +99,10 @@ def broadcast_object(obj, src: int = 0):
     if dist is None or dist.get_world_size() == 1:
         return obj
     box = [obj if dist.get_rank() == src else None]
-    dist.broadcast_object_list(box, src=src)
+    if dist.get_backend() == "nccl":  # the object travels through this rank's GPU: name it (torch's current device may be another)
+        import torch
+
+        dist.broadcast_object_list(box, src=src, device=torch.device("cuda", local_device_index()))
+    else:
+        dist.broadcast_object_list(box, src=src)
     return box[0]
