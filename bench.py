@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5) on both catalogues")
     ap.add_argument("--kpc", action="store_true", help="physical scales 100-1000 kpc (thresholds differ from bin to bin) instead of 1-10 arcmin")
     ap.add_argument("--rweight", type=float, default=None, help="separation weight r**rweight (Configuration rweight; resolution 50)")
+    ap.add_argument("--no-probe", action="store_true", help="with --gpus > 1: skip the scaling probe (BASELINE config #5) beside the headline")
     return ap.parse_args()
 
 
@@ -216,6 +217,50 @@ def exact_sample(links, ref, unk, n_jobs=2):
                 frac=tf / (FP64_VECTOR_PEAK_TFLOPS / 2.0), pairs_per_s=st.candidate_pairs / k_s,
                 parity_with_default_path=bool(np.array_equal(f_exact, f_default)),
                 note="8 non-FMA FP64 flop per candidate pair against half the FP64 vector peak (SURVEY.md 8(d))")
+
+
+def scaling_probe(steps, warmup, barrier, dist, world, rank):
+    """With N > 1 ranks the headline call (0.35 ms of count kernel, ~0.2 ms of fixed cost per call) is too short to show
+    what N GPUs buy; the same run therefore also times BASELINE config #5 (50M x 50M, 128 patches, 3 log scales: ~18 ms of
+    count kernel on one GPU), sharded and reduced exactly like the headline. Returns the record rank 0 prints as
+    ``scaling_probe`` inside the one JSON line."""
+    import types
+
+    import torch
+
+    from yet_another_wizz_amd import PatchLinkage
+
+    args5 = types.SimpleNamespace(n_ref=50e6, n_unk=50e6, patches=128, zbins=30, scales=3, weights=False)
+    t0 = time.perf_counter()
+    config, ref, unk = make_catalogs(args5)
+    ref.build_trees(config.binning.edges, closed=config.binning.closed)
+    unk.build_trees(None)
+    links = PatchLinkage.from_catalogs(config, ref, unk)
+    setup_s = time.perf_counter() - t0
+    for _ in range(max(warmup, 1)):
+        links.count_pairs(ref, unk)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        links.count_pairs(ref, unk)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stats = links.last_stats
+    stat_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    tens = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+    work = torch.tensor([float(stats.candidate_pairs), float(stats.count_ms)], dtype=torch.float64, device=stat_dev)
+    dist.all_reduce(tens, op=dist.ReduceOp.MAX)
+    cand = work.clone()
+    dist.all_reduce(cand, op=dist.ReduceOp.SUM)
+    dist.all_reduce(work, op=dist.ReduceOp.MAX)
+    elapsed = float(tens[0])
+    ref.drop_layouts()
+    unk.drop_layouts()
+    return dict(workload="50000000 ref x 50000000 unk uniform full sky, 30 z-bins, 128 patches, 3 log scales 0.5-15.8 arcmin, "
+                         "DD count of crosscorrelate (BASELINE config #5)",
+                metric="candidate pairs/s", value=float(cand[0]) * steps / elapsed, unit="pairs/s", n_gpus=world, steps=steps,
+                ms_per_step=elapsed / steps * 1e3, slowest_rank_count_kernel_ms=float(work[1]), setup_s=setup_s,
+                scaling="strong")
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -415,6 +460,14 @@ def main():
             candidate_pairs_per_step=cand, evaluated_pairs_per_step=evaluated,
             kernel_ms_per_step=kernel_ms_step, setup_s=setup_s, upload_s=upload_s, roofline=roofline, cpu_baseline=base,
         )
+    probe = None
+    if world > 1 and not args.no_probe:
+        ref.drop_layouts()
+        unk.drop_layouts()
+        probe = scaling_probe(min(max(args.steps, 1), 5), 1, barrier, dist, world, rank)
+    if rank == 0:
+        if probe is not None:
+            line["scaling_probe"] = probe
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

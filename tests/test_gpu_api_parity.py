@@ -14,6 +14,35 @@ def test_full_driver_vs_reference_on_gpu(tag, cfg, closed):
     helpers.run_full_case(tag, cfg, closed)
 
 
+@pytest.mark.parametrize("unit,rmin,rmax", [("kpc/h", [150.0, 600.0], [900.0, 2400.0]), ("Mpc/h", [0.2], [1.5]), ("Mpc", [0.15], [1.2])])
+def test_comoving_and_mpc_units_device_vs_oracle(unit, rmin, rmax, monkeypatch):
+    """Scales in comoving units (reference src/yaw/cosmology.py:262-285: scale / D_C(z) per redshift bin) and in Mpc through
+    the public API on the HIP path, against the CPU oracle fed the same thresholds; the distances themselves are pinned by
+    tests/test_cosmology.py."""
+    import yet_another_wizz_amd as yaw
+
+    rng = np.random.default_rng(len(unit))
+    def frame(n, with_z):
+        d = {"ra": rng.uniform(20.0, 26.0, n), "dec": rng.uniform(-3.0, 3.0, n)}
+        if with_z:
+            d["z"] = rng.uniform(0.15, 0.95, n)
+        return d
+    ref = yaw.Catalog.from_dataframe(None, frame(7000, True), ra_name="ra", dec_name="dec", redshift_name="z", patch_num=5)
+    make = lambda n, z: yaw.Catalog.from_dataframe(None, frame(n, z), ra_name="ra", dec_name="dec", redshift_name="z" if z else None,
+                                                   patch_centers=ref)
+    unk, rand = make(9000, False), make(14000, False)
+    config = yaw.Configuration.create(rmin=rmin, rmax=rmax, unit=unit, zmin=0.2, zmax=0.9, num_bins=5)
+    dev = yaw.crosscorrelate(config, ref, unk, unk_rand=rand)
+    helpers.use_oracle_engine(monkeypatch)
+    ora = yaw.crosscorrelate(config, ref, unk, unk_rand=rand)
+    assert len(dev) == len(ora) == len(rmin)
+    for cd, co in zip(dev, ora):
+        for kind in ("dd", "dr"):
+            assert np.array_equal(getattr(cd, kind).counts.counts, getattr(co, kind).counts.counts), (unit, kind)
+        assert co.dd.counts.counts.sum() > 500
+        np.testing.assert_allclose(cd.sample().data, co.sample().data, rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
 def test_twodflens_vs_reference_on_gpu():
     helpers.run_twodflens_case()
 

@@ -14,7 +14,7 @@ unk.build_trees(None)
 links = yaw.PatchLinkage.from_catalogs(config, ref, unk)
 for _ in range(3):
     links.count_pairs(ref, unk)
-orig = engine.count_fine
+orig = engine.count_dense
 acc = {"fine": 0.0, "lib_total": 0.0, "lib_kernel": 0.0}
 def timed(*a, **k):
     t0 = time.perf_counter()
@@ -23,14 +23,14 @@ def timed(*a, **k):
     acc["lib_total"] += out[1].total_ms * 1e-3
     acc["lib_kernel"] += out[1].kernel_ms * 1e-3
     return out
-engine.count_fine = timed
-measurements.engine.count_fine = timed
+engine.count_dense = timed
+measurements.engine.count_dense = timed
 n = 50
 t0 = time.perf_counter()
 for _ in range(n):
     links.count_pairs(ref, unk)
 tot = time.perf_counter() - t0
-print(f"per call: count_pairs {tot/n*1e3:.3f} ms | engine.count_fine {acc['fine']/n*1e3:.3f} | library wall {acc['lib_total']/n*1e3:.3f} | "
+print(f"per call: count_pairs {tot/n*1e3:.3f} ms | engine.count_dense {acc['fine']/n*1e3:.3f} | library wall {acc['lib_total']/n*1e3:.3f} | "
       f"device {acc['lib_kernel']/n*1e3:.3f} | python around the library {(acc['fine']-acc['lib_total'])/n*1e3:.3f} | "
       f"python epilogue {(tot-acc['fine'])/n*1e3:.3f}")
 import cProfile, pstats

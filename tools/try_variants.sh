@@ -1,5 +1,5 @@
 # A/B of compile-time variants (and run-time options) on ONE device (timings from different boxes differ by ~10 %)
-#   tools/try_variants.sh "-DYAW_MWG=64|--strip-micro 5000 --tile-r 1" "-DYAW_MWG=256|..." ...
+#   tools/try_variants.sh "-DYAW_MSTAGE=64|--strip-micro 5000 --tile-r 1" "-DYAW_MSTAGE=128|..." ...   (YAW_MWG is fixed at 64)
 set -e
 cd ${GRAFT_REPO_ROOT:-.}
 # whatever happens, leave the default build behind (build.py also refuses to treat a library built with other flags as fresh)

@@ -336,13 +336,21 @@ class Catalog(Mapping):
         # these values -- the exact host numbers the pair predicate runs on)
         xyz = radec_to_xyz(ra, dec) if xyz is None else tuple(np.asarray(c, dtype=np.float64) for c in xyz)
         columns = [ra, dec, *xyz] + [c for c in (weights, redshifts) if c is not None]
+        grouped = False
         if np.all(patch_ids[1:] >= patch_ids[:-1]):
-            pass  # already grouped by patch (a restored cache): the stable order is the identity, no gather
+            # already grouped by patch (a restored cache): the stable order is the identity. The catalogue keeps its own copy
+            # of the columns all the same -- a later change of the caller's arrays must not reach into it
+            columns = [np.array(c, dtype=np.float64, copy=True) for c in columns]
+            grouped = True
         elif len(ra) >= HOST_GROUP_MIN:  # one threaded counting sort over all columns (yawhip_host_group_columns)
             from . import _lib
 
-            columns, _ = _lib.group_columns(patch_ids, num, columns)
-        else:
+            try:
+                columns, _ = _lib.group_columns(patch_ids, num, columns)
+                grouped = True
+            except _lib.YawhipError:  # no library on this machine: catalogue preparation is host work, numpy does it too
+                pass
+        if not grouped:
             order = _stable_argsort_small(patch_ids, num)
             columns = [c[order] for c in columns]
         self._ra, self._dec, self._xyz = columns[0], columns[1], tuple(columns[2:5])
@@ -562,13 +570,18 @@ class Catalog(Mapping):
             patch_of = np.repeat(np.arange(num_patches), np.diff(self._patch_off))
             offsets = np.zeros(num_patches * num_bins + 1, dtype=np.int64)
             columns = [x, y, z] + ([] if self._w is None else [self._w])
+            grouped = False
             if len(x) >= HOST_GROUP_MIN:  # (patch, bin) grouping in one threaded pass; objects outside the binning dropped
                 from . import _lib
 
                 seg_key = np.where(bin_idx >= 0, patch_of * num_bins + bin_idx, -1)
-                columns, sizes = _lib.group_columns(seg_key, num_patches * num_bins, columns)
-                np.cumsum(sizes, out=offsets[1:])
-            else:
+                try:
+                    columns, sizes = _lib.group_columns(seg_key, num_patches * num_bins, columns)
+                    np.cumsum(sizes, out=offsets[1:])
+                    grouped = True
+                except _lib.YawhipError:  # no library on this machine: numpy below
+                    pass
+            if not grouped:
                 keep = np.flatnonzero(bin_idx >= 0)
                 seg_key = patch_of[keep] * num_bins + bin_idx[keep]
                 order = keep[_stable_argsort_small(seg_key, num_patches * num_bins)]

@@ -41,6 +41,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <system_error>
@@ -61,6 +62,7 @@ constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
 #define YAW_MWG 64
 #endif
 constexpr int MWG = YAW_MWG;        // threads per workgroup of the lean kernel (k_count_merged)
+static_assert(MWG == 64, "the band kernels are single-wave workgroups: their lane tile is 64 * R objects");
 constexpr int MSTAGE = YAW_MSTAGE;  // stage of the merged path: smaller -> less LDS -> more workgroups per CU
 constexpr int MAX_EDGES = 512;
 constexpr int SEG_STRIPS_MIN_RUN = 16;  // mean objects per (patch, bin, strip) run of the lane side from which mode 3 is used
@@ -142,6 +144,12 @@ typedef const __attribute__((address_space(1))) int32_t *gi32p;
 typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_PREFETCH
 #define YAW_B32_PREFETCH 0  // next trip's LDS reads issued before this trip's arithmetic: 0.404 against 0.379 ms (registers -> 5 waves)
+#endif
+#ifndef YAW_B32_UNROLL
+#define YAW_B32_UNROLL 1  // entries per trip of the walk loop: 1, 2 and 4 measure the same (0.362 / 0.366 / 0.374 ms at the headline)
+#endif
+#ifndef YAW_B32_WAVES_W
+#define YAW_B32_WAVES_W 1  // waves per SIMD the weighted one-annulus variants are compiled for (1: the compiler's choice)
 #endif
 #ifndef YAW_B32_WAVES
 #define YAW_B32_WAVES 1  // > 1: waves per SIMD every variant is compiled for (experiments). Default: 7 for the plain count (72 VGPRs
@@ -957,7 +965,7 @@ constexpr int BCAP = YAW_BCAP;  // window objects per LDS stage. 192: the window
                                 // entries + one band) fits in one stage; 6.2 KB -> 26 single-wave workgroups per CU. Measured
                                 // 160 / 176 / 192 / 208 / 224: count kernel 0.545 / 0.529 / 0.523 / 0.535 / 0.531 ms at the headline
 constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
-constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries
+constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries, [9 + 8 i] exact re-evaluations
 
 // LDS image of a band workgroup. The staged window lives in float64 SoA columns filled by LDS-DMA (global_load_lds_dwordx4:
 // 16 bytes per lane straight from HBM into LDS, no staging registers, no ds_write), one entry of slack per column for the
@@ -1413,7 +1421,8 @@ __host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots,
 // (rare: kept out of line so that its addresses and temporaries do not live in the walk loop's registers).
 __device__ __attribute__((noinline)) double band32_exact_s(gf64p lx, gf64p ly, gf64p lz, int64_t li, gf64p sx, gf64p sy, gf64p sz,
                                                            int64_t gi, unsigned long long *__restrict__ counters) {
-    atomicAdd(&counters[2], 1ull);  // statistics: evaluations decided by the exact predicate
+    atomicAdd(counters, 1ull);  // statistics: evaluations decided by the exact predicate (the caller passes one of EVAL_SLOTS
+                                // counters: tens of thousands of adds per launch on ONE address cost 0.4 ms at the headline)
     const double dx = lx[li] - sx[gi], dy = ly[li] - sy[gi], dz = lz[li] - sz[gi];
     const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
     const double sxy = xx + yy;
@@ -1435,7 +1444,7 @@ constexpr int B32_CAP_BIG = YAW_B32_CAP_BIG;
 constexpr int B32_MAX_CHUNKS = 3;  // windows (or pieces of one) staged together in one round of k_count_band32
 
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED && NE == 2 && UNI ? 7 : 1))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 && UNI ? (WEIGHTED ? YAW_B32_WAVES_W : 7) : 1))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                      const double *__restrict__ t, const float *__restrict__ thr32,
                                                      const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
                                                      unsigned long long *__restrict__ out_counts,
@@ -1544,7 +1553,6 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
         // lane objects while the stage is in flight: R NEIGHBOURING objects of the u-sorted tile per lane
         f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
         float ax[R], ay[R], az[R];
-        double aw[R];
         int kb[R];
         int n_own = (int)it.na - lane * R;
         n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
@@ -1556,7 +1564,6 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
             ay[r] = have ? (cl.qy + it.a0)[ic] : PAD_COORD32;
             az[r] = have ? (cl.qz + it.a0)[ic] : PAD_COORD32;
             kb[r] = MERGED ? (have ? (cl.k + it.a0)[ic] : 0) : 0;
-            aw[r] = (WEIGHTED && cl.w) ? (have ? (cl.w + it.a0)[ic] : 0.0) : (have ? 1.0 : 0.0);
         }
         // thresholds: per lane object (its bin's row from the LDS table) or one row for the wave
         float th[R][TW];
@@ -1601,8 +1608,10 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                         const double vsum = NE == 2 ? acc[r][0] : acc[r][f + 1] - acc[r][f];
                         // float64 adds of ONE instruction that hit the same cell are serialised by the LDS in a fixed lane
                         // order; the histogram belongs to this wave alone -> reproducible sums
+                        // (the object's own weight is fetched here, once per item, instead of living in registers through the walk)
+                        const double aw = (cl.w && r < n_own) ? (cl.w + it.a0)[lane * R + r] : 1.0;
                         if (vsum != 0.0)
-                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * vsum,
+                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw * vsum,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
                         const unsigned int c = NE == 2 ? cnt[r][0] : cnt[r][f + 1] - cnt[r][f];
@@ -1688,11 +1697,11 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
             const unsigned a_chunk = a_stage + ((unsigned)co[c] << 2);
             unsigned cur = a_chunk + ((unsigned)lo << 2);
             const unsigned last = a_chunk + ((unsigned)n << 2);
-            // One entry per trip: three 4-byte reads from columns a fixed distance apart (lanes read nearly consecutive words
-            // of a column).
-            for (int s = 0; s < steps; ++s) {
-                const unsigned a16 = cur < last ? cur : last;
-                cur += 4;
+            // One entry per evaluation step: three 4-byte reads from columns a fixed distance apart (lanes read nearly
+            // consecutive words of a column). YAW_B32_UNROLL entries per trip of the loop: their LDS reads go out together and the
+            // loop's own instructions are shared (a trip past the end of the longest band meets entries beyond every band,
+            // or the sentinel: they fail the predicate by themselves).
+            auto eval_entry = [&](const unsigned a16) {
                 struct { float x, y, z; } en;
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -1
                 en.x = klo; en.y = khi; en.z = klo;  // diagnostics: the walk's arithmetic without its LDS reads (wrong counts)
@@ -1705,7 +1714,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                 const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) << 1) + a_sw) : 1.0;
 #if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -2
                 cnt[0][0] += __float_as_uint(en.x) ^ __float_as_uint(en.y) ^ __float_as_uint(en.z);  // diagnostics: the LDS reads alone
-                continue;
+                return;
 #endif
                 float s32[R];
                 if constexpr (R >= 2) {
@@ -1729,7 +1738,9 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                         const float q = __builtin_fabsf(s32[r] - th[r][0]);
                         const bool in = q < th[r][1];
                         unc_mask[r] = __builtin_amdgcn_ballot_w64(q < th[r][2]) & ~__builtin_amdgcn_ballot_w64(in);
-                        if constexpr (WEIGHTED) acc[r][0] += in ? ew : 0.0;
+                        // weighted: acc += w of the entry where inside -- as an fma with the multiplier 1.0 / 0.0 (exact: the same
+                        // rounding as the add; one select instead of two on the 64-bit operand)
+                        if constexpr (WEIGHTED) acc[r][0] = __builtin_fma(in ? 1.0 : 0.0, ew, acc[r][0]);
                         else cnt[r][0] += in ? 1u : 0u;
                     } else {
                         unc_mask[r] = 0ull;
@@ -1737,7 +1748,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                         for (int e = 0; e < NE; ++e) {
                             const bool le = s32[r] < th[r][2 * e];  // certainly s <= t_e
                             unc_mask[r] |= __builtin_amdgcn_ballot_w64(s32[r] <= th[r][2 * e + 1]) & ~__builtin_amdgcn_ballot_w64(le);
-                            if constexpr (WEIGHTED) acc[r][e] += le ? ew : 0.0;
+                            if constexpr (WEIGHTED) acc[r][e] = __builtin_fma(le ? 1.0 : 0.0, ew, acc[r][e]);
                             else cnt[r][e] += le ? 1u : 0u;
                         }
                     }
@@ -1749,7 +1760,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx, counters);
+                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx, counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
                             const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
                             if constexpr (NE == 2) {
                                 const bool in = sd > tk[0] && sd <= tk[1];
@@ -1767,6 +1778,14 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (!WEIGHTED
                         }
                     }
                 }
+            };
+            for (int s = 0; s < steps; s += YAW_B32_UNROLL) {
+#pragma unroll
+                for (int uu = 0; uu < YAW_B32_UNROLL; ++uu) {
+                    const unsigned at = cur + 4u * (unsigned)uu;
+                    eval_entry(at < last ? at : last);
+                }
+                cur += 4u * YAW_B32_UNROLL;
             }
             }
             }
@@ -2016,7 +2035,7 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                             if (!(s32[r] < tm) && !(s32[r] > tp)) {  // inside the guard band of edge j
                                 bin = -1;
                                 if (eidx < (unsigned)n && r < n_own) {
-                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx, counters);
+                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx, counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
                                     const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * n_edges;
                                     bin = sd <= tk[j] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
                                     if (bin >= 0 && !(sd > tk[bin])) bin = -1;        // (degenerate tables: equal edges)
@@ -3567,7 +3586,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // 32-bit LDS counters: one stage adds at most 64 R x CAP to a cell, so flush at the latest every
         // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 192-entry stages, 2^15 for four and 288)
         int flush_log2 = ctx->flush_log2;
-        while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) > (1ull << 32)) --flush_log2;
+        while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) >= (1ull << 32)) --flush_log2;
         const unsigned flush_mask = (1u << flush_log2) - 1u;
         const size_t lds_band32 = band32_lds(weighted_any, cap, lean_bins * nf, merged && !uniform_t ? n_bins : 0, n_edges);
         auto launch_band32 = [&](bool wgt) -> hipError_t {
@@ -3837,7 +3856,8 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         stats->layout_mode = cs.mode;
         stats->n_orientations = cs.n_orient;
         stats->band_variant = cs.band_variant;
-        stats->exact_reevaluations = cs.band_ran ? (int64_t)ctr[2] : 0;
+        if (cs.band_ran)
+            for (int i = 0; i < EVAL_SLOTS; ++i) stats->exact_reevaluations += (int64_t)ctr[9 + 8 * (size_t)i];
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cs.wall0).count();
     }
@@ -4045,6 +4065,7 @@ int yawhip_count_pairs(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_c
         if (rc != YAWHIP_OK) { rc_all = rc; continue; }  // keep draining the other devices
         add_stats(total, part, true);
     }
+    (void)hipSetDevice(ctx->device);  // leave the thread on the context's first device, as single-device calls do
     if (rc_all != YAWHIP_OK) return rc_all;
     total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (stats) *stats = total;
@@ -4139,27 +4160,33 @@ int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const ya
         if (slices[2 * i] < 0 || slices[2 * i + 1] > nf)
             return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs_dense: slice %lld outside [0, %d]", (long long)i, nf);
     const int64_t P = c1->n_patches, row = (int64_t)n_bins * nf;
-    std::vector<double> fine;
-    try {
-        fine.resize((size_t)std::max<int64_t>((int64_t)n_jobs * row, 1));
-    } catch (const std::bad_alloc &) {
-        return fail(YAWHIP_ERR_OOM, "yawhip_count_pairs_dense: out of host memory");
-    }
-    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, nullptr, fine.data(), stats);
+    // unweighted catalogues are counted in int64 and converted here (exact below 2^53, the reference's .astype(float64),
+    // trees.py:353): one kernel and half the device-to-host bytes less than asking the device for both
+    const bool weighted = c1->w != nullptr || c2->w != nullptr;
+    const size_t n_fine = (size_t)std::max<int64_t>((int64_t)n_jobs * row, 1);
+    std::unique_ptr<double[]> fine_s(weighted ? new (std::nothrow) double[n_fine] : nullptr);
+    std::unique_ptr<int64_t[]> fine_c(weighted ? nullptr : new (std::nothrow) int64_t[n_fine]);
+    if (!fine_s && !fine_c) return fail(YAWHIP_ERR_OOM, "yawhip_count_pairs_dense: out of host memory");
+    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_c.get(), fine_s.get(), stats);
     if (rc != YAWHIP_OK) return rc;
     // Host epilogue, O(jobs x B x E), of PatchLinkage.count_pairs (reference src/yaw/correlation/measurements.py:354-364 with
     // src/yaw/catalog/trees.py:358-362,134-160 applied per job): separation weights, per-scale sums of the fine bins, halving
     // of the doubly counted diagonal of an autocorrelation, scatter into [scale][bin][patch i][patch j]; unlinked slots are 0.
     memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
     std::vector<double> scaled((size_t)nf);
-    for (int64_t j = 0; j < n_jobs; ++j) {
-        const int64_t p = jobs[2 * j], q = jobs[2 * j + 1];
-        if (p < 0 || p >= P || q < 0 || q >= P) return fail(YAWHIP_ERR_INVALID, "job %lld has a patch id outside [0,%lld)", (long long)j, (long long)P);
-        const double f = (halve_diagonal && p == q) ? 0.5 : 1.0;
-        for (int k = 0; k < n_bins; ++k) {
-            const double *fk = fine.data() + (size_t)j * row + (size_t)k * nf;
-            if (fine_factors) {  // counts *= weights (trees.py:358-360), then the sums
-                const double *wk = fine_factors + (size_t)k * nf;
+    for (int64_t j = 0; j < n_jobs; ++j)
+        if (jobs[2 * j] < 0 || jobs[2 * j] >= P || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= P)
+            return fail(YAWHIP_ERR_INVALID, "job %lld has a patch id outside [0,%lld)", (long long)j, (long long)P);
+    for (int k = 0; k < n_bins; ++k) {  // bin by bin: the scattered writes of one pass stay inside S slices of [P, P]
+        const double *wk = fine_factors ? fine_factors + (size_t)k * nf : nullptr;
+        for (int64_t j = 0; j < n_jobs; ++j) {
+            const int64_t p = jobs[2 * j], q = jobs[2 * j + 1];
+            const double f = (halve_diagonal && p == q) ? 0.5 : 1.0;
+            const size_t at = (size_t)j * row + (size_t)k * nf;
+            const double *fk = weighted ? fine_s.get() + at : scaled.data();
+            if (!weighted)
+                for (int e = 0; e < nf; ++e) scaled[(size_t)e] = (double)fine_c[at + (size_t)e];
+            if (wk) {  // counts *= weights (trees.py:358-360), then the sums
                 for (int e = 0; e < nf; ++e) scaled[(size_t)e] = fk[e] * wk[e];
                 fk = scaled.data();
             }

@@ -25,7 +25,8 @@ def default_devices(max_workers: int | None = None) -> tuple:
     """GPUs one process counts on. Inside a ``torch.distributed`` group (one process per GPU) that is the process'
     own device; a single process takes every visible GPU (``YAW_AMD_DEVICES="0,1,2"`` picks them explicitly, an id
     may repeat) -- the counterpart of the reference's worker pool, so ``max_workers`` caps their number
-    (src/yaw/utils/parallel.py:145-150)."""
+    (src/yaw/utils/parallel.py:145-150). Launchers that start one process per GPU without setting LOCAL_RANK (mpirun,
+    srun) must set ``YAW_AMD_DEVICES`` (or ``YAW_AMD_DEVICE``) per process, or every process takes every GPU."""
     env = os.environ.get("YAW_AMD_DEVICES")
     if env:
         devices = [int(v) for v in env.split(",") if v.strip() != ""]
@@ -154,7 +155,7 @@ def assign_patches(xyz, centers_xyz):
     try:
         if _lib.device_count() < 1:
             return None
-        ctx = get_context()
+        ctx = get_context(default_devices()[0])  # one device does it: no reason to span (and replicate on) every GPU
     except _lib.YawhipError:
         return None
     if isinstance(xyz, tuple):  # three columns
