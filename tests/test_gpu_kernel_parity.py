@@ -719,6 +719,11 @@ def test_float32_guard_bands_are_decided_exactly(ctx, theta_deg, grid):
             counts, _, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band")
             assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == 1
             assert np.array_equal(counts, exp), fp32
+            # the engineered partners sit inside the guard bands: the exact predicate must have been called on for many of them
+            # (a fine grid over tens of degrees is not log-spaced in chord^2 any more -- sin -- and stays on the float64 kernel)
+            want = 64 if (not fp32 or (grid == "fine" and theta_deg > 10.0)) else (33 if grid == "fine" else 32)
+            assert st.band_variant == want
+            assert (st.exact_reevaluations > n // 20) if want != 64 else (st.exact_reevaluations == 0)
     finally:
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("band_fp32", 1)
@@ -798,6 +803,58 @@ def test_counts_beyond_32_bits_per_item(ctx):
             assert counts[0, 0, 0] == n1 * n2 > 2**32, kernel
     finally:
         ctx.set_option("tile_r", 0)
+
+
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+@pytest.mark.parametrize("grid", ["annulus", "two_scales", "fine"])
+def test_windows_longer_than_the_stage(ctx, grid, weights):
+    """A dense streamed side: the window of a lane tile holds ~1500 entries, several times the LDS stage of the band kernels
+    (320 / 512 entries, 192 / 288 for fine grids): it goes through the stage in pieces, the bands of a lane continue from
+    piece to piece, and the counters are flushed per round when ``flush_stages_log2`` says so. Merged items (binned x
+    unbinned) and per-bin items (binned x binned); bit parity / 1e-10 with the oracle."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(31 + len(grid))
+    B = 3
+    def cat(n, nb, w):
+        ra = np.deg2rad(rng.uniform(80.0, 80.5, n)); dec = np.deg2rad(rng.uniform(-20.0, -19.5, n))
+        z = rng.uniform(0.1, 0.9, n)
+        return oracle.sort_catalog(ra, dec, z, rng.uniform(0.5, 1.5, n) if w else None, (ra > np.deg2rad(80.25)).astype(int), 2,
+                                   np.linspace(0.1, 0.9, nb + 1) if nb > 1 else None, "right")
+    c1 = cat(12000, B, weights[0] == "w")
+    th = 3.0 * np.pi / 10800
+    if grid == "annulus":
+        ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th], [th]), None, None)
+    elif grid == "two_scales":
+        ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th, 0.3 * th], [0.4 * th, th]), None, None)
+    else:
+        ab = oracle.ang_bins_for(oracle.parse_ang_limits([0.1 * th], [th]), -1.0, 16)
+    t = np.tile(oracle.thresholds_for(ab), (B, 1))
+    jobs = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.int32)
+    micro = int(min(max(np.ceil(1.02e6 * np.sqrt(t.max()) / 50.0) * 50.0, 1000), 2000000))
+    try:
+        ctx.set_option("strip_width_micro", micro)
+        ctx.set_option("seg_strips_min_run", 1)
+        d1 = _lib.DeviceCatalog(ctx, c1["x"], c1["y"], c1["z"], c1["w"], 2, B, c1["off"])
+        for nb2, n2 in ((1, 60000), (B, 90000)):
+            c2 = cat(n2, nb2, weights[1] == "w")
+            d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], c2["w"], 2, nb2, c2["off"])
+            exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+            assert exp_c.sum() > 1e6
+            for log2 in (17, 0):
+                ctx.set_option("flush_stages_log2", log2)
+                counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == (1 if nb2 == 1 else 3)
+                assert st.band_variant == (33 if grid == "fine" else 32)
+                assert np.array_equal(counts, exp_c), (nb2, log2)
+                if weights == "uu":
+                    assert np.array_equal(sums, exp_c.astype(np.float64))
+                else:
+                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+    finally:
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+        ctx.set_option("seg_strips_min_run", 16)
+        ctx.set_option("flush_stages_log2", 17)
 
 
 def test_band_kernel_flush_interval(ctx):

@@ -380,11 +380,15 @@ class PatchLinkage:
         """The reference logs every pair count and shows a progress bar over its patch-pair tasks
         (src/yaw/correlation/measurements.py:53-62,344-350); one GPU call has no tasks to tick off, so ``progress`` prints
         one summary line per count instead. Rank 0 only."""
+        if not progress and not logger.isEnabledFor(logging.INFO):
+            return  # nobody listens: the line is not even formatted (a pair count can be a 0.5 ms call)
+        if parallel.world()[0] != 0:
+            return
         secs = max(stats.total_ms, 1e-6) / 1e3
         line = (f"{what or 'pair count'}: {n_jobs} patch pairs, {stats.candidate_pairs:.4g} candidate pairs in "
                 f"{stats.total_ms:.2f} ms ({stats.candidate_pairs / secs:.3g} pairs/s)")
-        _log_info(line)
-        if progress and parallel.world()[0] == 0:
+        logger.info(line)
+        if progress:
             print(line, flush=True)
 
     def count_pairs_optional(self, main_catalog, *optional_catalog, **kwargs):
