@@ -328,6 +328,15 @@ def main():
     engine.device_catalog(ref._active_layout, sort_axis=links.sort_axis, strip_micro=micro, exact=True)
     engine.device_catalog(unk._active_layout, sort_axis=links.sort_axis, strip_micro=micro, exact=True)
     upload_s = time.perf_counter() - t_up
+    # Housekeeping of the interpreter, not of the path: a generation-2 garbage collection walks every object of the imported
+    # modules (torch brings about a million) and takes ~40 ms -- when the allocation counters happen to trigger one inside a
+    # 3 - 11 ms timed region the step time reads 5 x too long (seen on the 1M x 1M configuration). Collect now, and keep what
+    # exists out of later collections.
+    import gc
+
+    gc.collect()
+    gc.freeze()
+    barrier()
     for _ in range(max(args.warmup, 0)):
         step()
     barrier()

@@ -60,7 +60,10 @@ for sub in ("sq1", "sq2"):
             if "k_count" in row["Kernel_Name"]:
                 seen[row["Counter_Name"]] = float(row["Counter_Value"])
                 dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-                kname = row["Kernel_Name"].split("(")[0]
+                import re
+
+                m = re.search(r"k_count\w*(<[^>]*>)?", row["Kernel_Name"])
+                kname = m.group(0) if m else row["Kernel_Name"][:80]
     if seen:
         sq[sub] = dict(kernel_ms_under_pmc=dur / 1e6, kernel=kname, **seen)
 if sq:
