@@ -162,12 +162,67 @@ struct DevTab {
     gi32p k;                   // bin id per object (merged cross-correlation layouts), else null
     gi64p off;                 // run offsets [V+1] (strip layouts) or segment offsets
     gi64p vbase, slo, tiles;   // strip layouts: first run of a group, its grid index, lane-tile prefix over runs
-    gi32p tile_run;            // strip layouts: run of every lane tile
+    const struct TileRec *tile_rec;  // strip layouts: first object, length and run of every lane tile
+    const struct RunGrid *grid;      // strip layouts: per-run index along the sort axis (item builder)
     gf32p qx, qy, qz;          // strip layouts: float32 images of the columns (k_count_band32)
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
 __device__ __forceinline__ gf64p tab_key(const DevTab &t) { return t.axis == 0 ? t.x : (t.axis == 1 ? t.y : t.z); }
+
+// Tables of the strip item builder. Every thread of the builder walks a chain of dependent loads and the chain's length
+// is the kernel's run time (0.06 of the 0.55 ms of a headline call), so what the host or the layout build can precompute
+// travels as one record per job, per lane tile and per run instead of being looked up table by table.
+struct TileRec {   // per lane tile of a layout (one table per tile size)
+    int64_t a0;    // first object
+    int32_t na;    // objects (<= tile)
+    int32_t run;   // run the tile belongs to
+};
+struct JobRec {    // per job of a call
+    int64_t t_lo;      // first lane tile of the job (absolute index into the lane side's tile table)
+    int64_t k_off;     // strip of the streamed group facing lane run r2 under neighbour offset d: r2 + k_off + d
+    int64_t vbase1;    // first run of the streamed group
+    int32_t n_strips1; // runs of the streamed group
+    int32_t o;         // orientation: which pair of layouts the job runs on
+};
+// Per-run index along the sort axis: the key range [first, last] of a run is cut into RUN_GRID cells by
+// cell(key) = clamp(floor((key - first) * inv), 0, RUN_GRID - 1), and g[c] = number of entries whose cell is < c
+// (g[0] = 0, g[RUN_GRID] = run length). cell() is monotone in the key and evaluated by the same instructions when the
+// table is built and when it is queried, so for any w the first entry with key >= w and the first with key > w both lie in
+// [g[cell(w)], g[cell(w) + 1]] -- exactly, whatever the rounding of the product: the bisection over a run of 900 entries
+// (ten dependent loads) becomes one table look-up and four steps.
+constexpr int RUN_GRID = 64;
+struct RunGrid {
+    double inv;                  // RUN_GRID / (last - first), 0 for a run with one distinct key
+    uint32_t g[RUN_GRID + 2];    // + 1 pad: 8-byte multiple
+};
+__device__ __forceinline__ int run_cell(double key, double first, double inv) {
+    const double f = (key - first) * inv;
+    return f >= (double)RUN_GRID ? RUN_GRID - 1 : (f >= 1.0 ? (int)f : 0);
+}
+// one thread per (run, cell boundary): g[c] by bisection with the predicate cell(key) < c
+__global__ __launch_bounds__(256) void k_run_grid(int64_t n_runs, const int64_t *__restrict__ off, const double *__restrict__ key,
+                                                  RunGrid *__restrict__ grid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = i / (RUN_GRID + 1);
+    const int c = (int)(i - r * (RUN_GRID + 1));
+    if (r >= n_runs) return;
+    const int64_t b0 = off[r], b1 = off[r + 1];
+    double inv = 0.0, first = 0.0;
+    if (b1 > b0) {
+        first = key[b0];
+        const double span = key[b1 - 1] - first;
+        inv = span > 0.0 ? (double)RUN_GRID / span : 0.0;
+        if (!(inv < 1e300)) inv = 0.0;  // a denormal span: one cell
+    }
+    int64_t l = b0, h = b1;
+    while (l < h) {
+        const int64_t m = (l + h) >> 1;
+        if (run_cell(key[m], first, inv) < c) l = m + 1; else h = m;
+    }
+    grid[r].g[c] = (uint32_t)(l - b0);
+    if (c == 0) { grid[r].inv = inv; grid[r].g[RUN_GRID + 1] = 0; }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Item builder: one thread per potential item (slot, lane tile).
@@ -179,11 +234,15 @@ __device__ __forceinline__ gf64p tab_key(const DevTab &t) { return t.axis == 0 ?
 //                  s = fl(fl(dx^2 + dy^2) + dz^2) >= dz^2 (1 - 3 eps). Items with an empty window are
 //                  dropped; survivors are appended with one atomic per workgroup (order is irrelevant).
 // ------------------------------------------------------------------------------------------------
+constexpr int EVAL_SLOTS = 256;  // statistics counters, one 64-byte line each (a single hot address would serialise)
 constexpr int BUILD_WG = 1024;       // most threads per workgroup of the item builders
 // Builder workgroups: one atomic per workgroup appends its items, so few large workgroups suit long lists (16 k atomics on
 // the one counter cost 0.15 ms at 4 M potential items), but 1024 threads make 300 workgroups for 256 CUs at the headline
 // and half the chip waits for the CUs that got two (+0.07 ms): 256 threads while that keeps the atomics below 4096.
-inline int build_wg_for(int64_t n_pot) { return n_pot / 256 <= 4096 ? 256 : BUILD_WG; }
+#ifndef YAW_BUILD_WG_SMALL
+#define YAW_BUILD_WG_SMALL 256
+#endif
+inline int build_wg_for(int64_t n_pot) { return n_pot / 256 <= 4096 ? YAW_BUILD_WG_SMALL : BUILD_WG; }
 constexpr int BUILD_PREFIX_LDS = 1024;  // job tables up to this many entries are searched in LDS by the strip builder (8 KB: no occupancy cost)
 
 // Append the kept items of a builder workgroup to the item list and add its evaluated-pair total: ONE atomic
@@ -212,7 +271,7 @@ __device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned
             wsum += s_work[wv];
         }
         s_base = total ? atomicAdd(&counters[0], (unsigned long long)total) : 0ull;
-        if (wsum) atomicAdd(&counters[1], wsum);
+        if (wsum) atomicAdd(&counters[10 + 8 * (blockIdx.x & (EVAL_SLOTS - 1))], wsum);  // statistics, spread like the other totals
     }
     __syncthreads();
     if (keep) items[s_base + s_cnt[wave] + __popcll(mask & ((1ull << lane) - 1ull))] = it;
@@ -277,8 +336,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
 // job (prefix over jobs), its tile (prefix of tiles over the runs of c2) and the strip of c1 on the common
 // grid; window search and compaction as in k_build_items<true>.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *__restrict__ tabs, const int32_t *__restrict__ jobs,
-                                                            const int32_t *__restrict__ job_runs,
+__global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *__restrict__ tabs, const JobRec *__restrict__ jobs,
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
                                                             int tile, double rwin, int swap, int64_t n_pot,
                                                             Item *__restrict__ items, unsigned long long *__restrict__ counters,
@@ -287,7 +345,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
     bool keep = false;
     Item it{};
     unsigned long long work = 0;
-    // Every thread walks a chain of dependent loads (job -> run -> tile -> windows); its length is the kernel's run time.
+    // Every thread walks a chain of dependent loads (job -> tile -> runs -> windows); its length is the kernel's run time.
     // The job table is small: searched in LDS (one coalesced load instead of log2(jobs) round trips to L2).
     __shared__ int64_t s_prefix[BUILD_PREFIX_LDS];
     const bool prefix_in_lds = n_jobs + 1 <= BUILD_PREFIX_LDS;
@@ -308,65 +366,80 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
                 if (prefix[mid] <= pot) lo = mid; else hi = mid;
             }
         }
+        const int job = lo;
+        const JobRec jr = jobs[job];
+        const int o = jr.o;  // orientation of the job: which pair of layouts it runs on
         // swap: the lane tiles come from the first catalogue of the job (the binned one), the windows from the second
-        const int job = lo, p = jobs[2 * job + swap], q = jobs[2 * job + 1 - swap];
-        const int o = job_runs[3 * job + 2];  // orientation of the job: which pair of layouts it runs on
         const DevTab &c1 = tabs[swap ? 3 + o : o], &c2 = tabs[swap ? o : 3 + o];
         const gf64p key1 = tab_key(c1), key2 = tab_key(c2);
-        // potential items of a job, in this order: run of patch q, group of neighbour offsets, lane tile of the run. One
-        // item carries up to MAX_WIN neighbouring strips of patch p (all 2 * reach + 1 = 3 of them when the grid is as
-        // wide as the largest separation): the lane tile is loaded once and its histogram flushed once for all of them.
+        // potential items of a job in the order (lane tile, group of neighbour offsets). One item carries up to MAX_WIN
+        // neighbouring strips of the streamed group (all 2 * reach + 1 = 3 of them when the grid is as wide as the
+        // largest separation): the lane tile is loaded once and its histogram flushed once for all of them.
         const int nd = 2 * reach + 1, ng = (nd + MAX_WIN - 1) / MAX_WIN;
-        // runs of patch q whose grid index is within reach of some strip of patch p (host: job_runs)
-        const int64_t r_lo = c2.vbase[q] + job_runs[3 * job];
-        const int64_t t_lo = c2.tiles[r_lo];
         const int64_t local = pot - (prefix_in_lds ? s_prefix[job] : prefix[job]);
-        // potential items of a job in the order (lane tile, group of neighbour offsets); the run of a tile comes from the
-        // layout's tile -> run table (one load; a search over the tile prefix was a third of this kernel's dependent loads)
-        const int g = (int)(local % ng);
-        const int64_t target = t_lo + local / ng;
-        const int64_t r2 = c2.tile_run[target];
-        const int64_t a_seg1 = c2.off[r2 + 1];
-        const int64_t a0 = c2.off[r2] + (target - c2.tiles[r2]) * (int64_t)tile;
-        const int64_t a1 = a0 + tile < a_seg1 ? a0 + tile : a_seg1;
+        // (a call has fewer than 2^31 potential items: 32-bit division, and none in the usual case of one group)
+        const uint32_t local32 = (uint32_t)local, tl = ng == 1 ? local32 : local32 / (uint32_t)ng;
+        const int g = (int)(local32 - tl * (uint32_t)ng);
+        const TileRec tr = c2.tile_rec[jr.t_lo + tl];
+        const int64_t r2 = tr.run, a0 = tr.a0, a1 = a0 + tr.na;
         const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
-        const int64_t n_strips1 = c1.vbase[p + 1] - c1.vbase[p];
-        it.a0 = a0; it.na = (int32_t)(a1 - a0); it.nwin = 0;
+        it.a0 = a0; it.na = tr.na; it.nwin = 0;
         it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
         // The windows of the (up to) three partner runs are searched in lockstep: three independent chains of loads per
         // thread instead of one after the other (static indices throughout: everything stays in registers).
-        int64_t wb[MAX_WIN], sl[MAX_WIN], sh[MAX_WIN], ul[MAX_WIN], uh[MAX_WIN];
+        // (bounds relative to the run's first entry, 32 bits: half the integer work of the search)
+        int64_t wb[MAX_WIN];
+        uint32_t sl[MAX_WIN], sh[MAX_WIN], ul[MAX_WIN], uh[MAX_WIN];
         int32_t wn[MAX_WIN];
 #pragma unroll
         for (int j = 0; j < MAX_WIN; ++j) {
             const int dd = g * MAX_WIN + j;
-            const int64_t s1 = c2.slo[q] + (r2 - c2.vbase[q]) + (dd - reach) - c1.slo[p];
-            const bool valid = dd < nd && s1 >= 0 && s1 < n_strips1;
-            const int64_t r1 = c1.vbase[p] + (valid ? s1 : 0);
-            const int64_t b0 = c1.off[r1], b1 = valid ? c1.off[r1 + 1] : b0;
+            const int64_t s1 = r2 + jr.k_off + (dd - reach);
+            const bool valid = dd < nd && s1 >= 0 && s1 < jr.n_strips1;
+            const int64_t r1 = jr.vbase1 + (valid ? s1 : 0);
+            int64_t b0 = 0, b1 = 0;
+            if (valid) { b0 = c1.off[r1]; b1 = c1.off[r1 + 1]; }
             // four partner runs in five lie entirely before or behind the tile's window (neighbouring patches share a
             // boundary only): two loads settle those
             const bool some = b1 > b0;
-            const double kfirst = key1[some ? b0 : 0], klast = key1[some ? b1 - 1 : 0];
+            // (loads under their condition: the texture path is what this kernel is bound by, and it charges the lanes of a
+            // load that are switched on; a wave whose tiles face no live run skips them altogether)
+            double kfirst = 0.0, klast = 0.0;
+            if (some) { kfirst = key1[b0]; klast = key1[b1 - 1]; }
             const bool live = some && !(klast < wlo || kfirst > whi);
-            sl[j] = ul[j] = b0;
-            sh[j] = uh[j] = live ? b1 : b0;
+            // the run's index along the sort axis narrows both searches to one cell (RunGrid)
+            uint32_t l0 = 0, l1 = 0, u0 = 0, u1 = 0;
+            if (live) {
+                const double inv = c1.grid[r1].inv;
+                const int cl = run_cell(wlo, kfirst, inv), cu = run_cell(whi, kfirst, inv);
+                const uint32_t *gr = c1.grid[r1].g;
+                l0 = gr[cl]; l1 = gr[cl + 1]; u0 = gr[cu]; u1 = gr[cu + 1];
+            }
+            wb[j] = b0;
+            sl[j] = l0; sh[j] = l1; ul[j] = u0; uh[j] = u1;  // all 0 for a dead window
         }
         // lower bounds (first index with key >= wlo) and upper bounds (first index with key > whi), all at once
         while ((sl[0] < sh[0]) | (sl[1] < sh[1]) | (sl[2] < sh[2]) | (ul[0] < uh[0]) | (ul[1] < uh[1]) | (ul[2] < uh[2])) {
+            double kl[MAX_WIN], ku[MAX_WIN];
+            uint32_t ml[MAX_WIN], mu[MAX_WIN];
 #pragma unroll
-            for (int j = 0; j < MAX_WIN; ++j) {
-                const bool gl = sl[j] < sh[j], gu = ul[j] < uh[j];
-                const int64_t ml = (sl[j] + sh[j]) >> 1, mu = (ul[j] + uh[j]) >> 1;
-                const double kl = key1[gl ? ml : 0], ku = key1[gu ? mu : 0];
-                if (gl) { if (kl < wlo) sl[j] = ml + 1; else sh[j] = ml; }
-                if (gu) { if (ku <= whi) ul[j] = mu + 1; else uh[j] = mu; }
+            for (int j = 0; j < MAX_WIN; ++j) {  // the six probes of a step are issued together ...
+                ml[j] = sl[j] + ((sh[j] - sl[j]) >> 1);
+                mu[j] = ul[j] + ((uh[j] - ul[j]) >> 1);
+                kl[j] = ku[j] = 0.0;
+                if (sl[j] < sh[j]) kl[j] = key1[wb[j] + ml[j]];
+                if (ul[j] < uh[j]) ku[j] = key1[wb[j] + mu[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < MAX_WIN; ++j) {  // ... and consumed after one wait
+                if (sl[j] < sh[j]) { if (kl[j] < wlo) sl[j] = ml[j] + 1; else sh[j] = ml[j]; }
+                if (ul[j] < uh[j]) { if (ku[j] <= whi) ul[j] = mu[j] + 1; else uh[j] = mu[j]; }
             }
         }
 #pragma unroll
         for (int j = 0; j < MAX_WIN; ++j) {
-            wb[j] = sl[j];
-            wn[j] = (int32_t)(ul[j] - sl[j]);  // 0 for a dead window (both bounds stay at b0)
+            wb[j] += sl[j];
+            wn[j] = (int32_t)(ul[j] - sl[j]);  // 0 for a dead window
         }
 #pragma unroll
         for (int j = 0; j < MAX_WIN; ++j) {  // non-empty windows to the front
@@ -964,8 +1037,7 @@ auto pick_count_merged() -> void (*)(YAW_COUNT_MERGED_ARGS) {
 constexpr int BCAP = YAW_BCAP;  // window objects per LDS stage. 192: the window of a 128-object lane tile at equal densities (128 +- 11
                                 // entries + one band) fits in one stage; 6.2 KB -> 26 single-wave workgroups per CU. Measured
                                 // 160 / 176 / 192 / 208 / 224: count kernel 0.545 / 0.529 / 0.523 / 0.535 / 0.531 ms at the headline
-constexpr int EVAL_SLOTS = 256;  // evaluated-entry counters, one 64-byte line each (a single hot address would serialise)
-constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [1] lane-tile x window pairs, [8 + 8 i] band entries, [9 + 8 i] exact re-evaluations
+constexpr int N_CTR = 8 + 8 * EVAL_SLOTS;  // counters: [0] kept items, [8 + 8 i] band entries, [9 + 8 i] exact re-evaluations, [10 + 8 i] lane-tile x window pairs
 
 // LDS image of a band workgroup. The staged window lives in float64 SoA columns filled by LDS-DMA (global_load_lds_dwordx4:
 // 16 bytes per lane straight from HBM into LDS, no staging registers, no ds_write), one entry of slack per column for the
@@ -2176,10 +2248,10 @@ __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, do
 }
 
 inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
-                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const int32_t *tile_run, int axis,
-                       const float *q = nullptr, int64_t q_stride = 0) {
+                       const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const TileRec *tile_rec, const RunGrid *grid,
+                       int axis, const float *q = nullptr, int64_t q_stride = 0) {
     return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
-                  (gi32p)tile_run, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), axis, 0};
+                  tile_rec, grid, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), axis, 0};
 }
 
 template <typename T>
@@ -2298,19 +2370,21 @@ struct StripLayout {
     std::vector<int64_t> h_slo;       // [G]   global strip index of a group's first run
     std::vector<int64_t> h_tiles[3];  // [V+1] prefix of lane tiles over the runs, for tiles of MWG * {1, 2, 4} objects
     int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
-    int32_t *d_tile_run[3] = {nullptr, nullptr, nullptr};  // [tiles] run of every lane tile (inverse of the tile prefix)
+    TileRec *d_tile_rec[3] = {nullptr, nullptr, nullptr};  // [tiles] first object, length and run of every lane tile
+    RunGrid *d_grid = nullptr;        // [V+1] per-run index along the sort axis (item builder)
     int64_t n_groups = 0;
     int64_t device_bytes = 0;
     double obj_run = 0.0;             // run length seen by the typical object (sum len^2 / sum len)
     double same_bin = 0.0;            // fraction of neighbours in the layout's order that share their bin (binned patch-level layouts)
     void release() {
         for (void *ptr : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)q, (void *)off, (void *)d_vbase, (void *)d_slo,
-                          (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_run[0], (void *)d_tile_run[1],
-                          (void *)d_tile_run[2]})
+                          (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_rec[0], (void *)d_tile_rec[1],
+                          (void *)d_tile_rec[2], (void *)d_grid})
             if (ptr) (void)hipFree(ptr);
         x = y = z = w = nullptr; k = nullptr; q = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
-        d_tile_run[0] = d_tile_run[1] = d_tile_run[2] = nullptr;
+        d_tile_rec[0] = d_tile_rec[1] = d_tile_rec[2] = nullptr;
+        d_grid = nullptr;
         built = false;
     }
 };
@@ -2659,6 +2733,8 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     L.q_stride = (int64_t)((n1 + 3) & ~(size_t)3) + 8;  // a 16-byte load of the band kernel may run up to 12 bytes past a column
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.q), (size_t)3 * L.q_stride * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off), (size_t)(n_runs + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_grid), (size_t)(n_runs + 1) * sizeof(RunGrid));
+    if (e == hipSuccess) e = hipMemsetAsync(L.d_grid, 0, (size_t)(n_runs + 1) * sizeof(RunGrid), ctx->stream);  // [V]: read for groups without runs
     if (e != hipSuccess) return bail(e, "strip layout");
     hipLaunchKernelGGL(k_gather_columns, dim3(ngrid), dim3(256), 0, ctx->stream, n, perm2, c->x, c->y, c->z, c->w, L.x, L.y, L.z, L.w);
     if (want_bins)
@@ -2666,6 +2742,9 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     hipLaunchKernelGGL(k_make_q, dim3(ngrid), dim3(256), 0, ctx->stream, n, L.x, L.y, L.z, L.q_stride, L.q);
     hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
                        L.off);
+    if (n_runs > 0)
+        hipLaunchKernelGGL(k_run_grid, dim3((unsigned)((n_runs * (RUN_GRID + 1) + 255) / 256)), dim3(256), 0, ctx->stream, n_runs, L.off,
+                           o == 0 ? L.x : (o == 1 ? L.y : L.z), L.d_grid);
     std::vector<int64_t> voff((size_t)n_runs + 1);
     e = hipMemcpyAsync(voff.data(), L.off, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
     unsigned long long h_same = 0;
@@ -2680,20 +2759,26 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(e, "run offsets");
     L.same_bin = n > 1 ? (double)h_same / (double)(n - 1) : 0.0;
+    for (int64_t r = 0; r < n_runs; ++r)
+        if (voff[(size_t)r + 1] - voff[(size_t)r] >= (1ll << 32)) return bail(hipErrorInvalidValue, "a strip run of 2^32 objects or more");
     // small per-run tables the item builder walks on the device
     for (int ri = 0; ri < 3; ++ri) {
         const int64_t tile = (int64_t)MWG << ri;
         L.h_tiles[ri].assign((size_t)n_runs + 1, 0);
         for (int64_t r = 0; r < n_runs; ++r)
             L.h_tiles[ri][(size_t)r + 1] = L.h_tiles[ri][(size_t)r] + (voff[(size_t)r + 1] - voff[(size_t)r] + tile - 1) / tile;
-        {  // run of every tile: the item builder decodes a potential item with one load instead of a search over the prefix
+        {  // record of every tile: the item builder decodes a potential item with one load instead of a search over the
+           // prefix and a look-up of the run's offsets
             const int64_t n_tiles = L.h_tiles[ri][(size_t)n_runs];
-            std::vector<int32_t> tile_run((size_t)std::max<int64_t>(n_tiles, 1));
+            std::vector<TileRec> tile_rec((size_t)std::max<int64_t>(n_tiles, 1), TileRec{0, 0, 0});
             for (int64_t r = 0; r < n_runs; ++r)
-                for (int64_t tl = L.h_tiles[ri][(size_t)r]; tl < L.h_tiles[ri][(size_t)r + 1]; ++tl) tile_run[(size_t)tl] = (int32_t)r;
-            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tile_run[ri]), tile_run.size() * sizeof(int32_t));
+                for (int64_t tl = L.h_tiles[ri][(size_t)r]; tl < L.h_tiles[ri][(size_t)r + 1]; ++tl) {
+                    const int64_t a0 = voff[(size_t)r] + (tl - L.h_tiles[ri][(size_t)r]) * tile;
+                    tile_rec[(size_t)tl] = TileRec{a0, (int32_t)std::min<int64_t>(tile, voff[(size_t)r + 1] - a0), (int32_t)r};
+                }
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tile_rec[ri]), tile_rec.size() * sizeof(TileRec));
             if (e == hipSuccess)
-                e = hipMemcpy(L.d_tile_run[ri], tile_run.data(), tile_run.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+                e = hipMemcpy(L.d_tile_rec[ri], tile_rec.data(), tile_rec.size() * sizeof(TileRec), hipMemcpyHostToDevice);
         }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_tiles[ri]), (size_t)(n_runs + 1) * sizeof(int64_t));
         if (e == hipSuccess)
@@ -2716,7 +2801,8 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     L.h_slo = std::move(slo);
     L.n_groups = n_groups;
     L.device_bytes = (int64_t)col * (c->w ? 4 : 3) + (want_bins ? n * (int64_t)sizeof(int32_t) : 0) + 3 * L.q_stride * (int64_t)sizeof(float) +
-                     (4 * (n_runs + 1) + 2 * (int64_t)n_groups + 1) * (int64_t)sizeof(int64_t);
+                     (4 * (n_runs + 1) + 2 * (int64_t)n_groups + 1) * (int64_t)sizeof(int64_t) + (n_runs + 1) * (int64_t)sizeof(RunGrid) +
+                     (L.h_tiles[0][(size_t)n_runs] + L.h_tiles[1][(size_t)n_runs] + L.h_tiles[2][(size_t)n_runs]) * (int64_t)sizeof(TileRec);
     c->device_bytes += L.device_bytes;
     L.built = true;
     return bail(hipSuccess, "");
@@ -3382,7 +3468,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     // strip path: slot = job; its potential items = (lane tiles of patch q) x (groups of up to MAX_WIN of the 2*reach+1
     // neighbouring strips), enumerated by the builder kernel from the catalogues' run tables.
     std::vector<int64_t> prefix;
-    std::vector<int32_t> job_runs;  // strip path, per job: first run of patch q (relative) and number of runs to visit
+    std::vector<JobRec> job_recs;  // strip path, per job: what the builder needs of the two groups (JobRec)
     int64_t n_items = 0, cand = 0, abytes = 0;
     const int obj_bytes1 = c1->w ? 32 : 24, obj_bytes2 = c2->w ? 32 : 24;
     int reach = 0;
@@ -3403,13 +3489,14 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 sjobs[(size_t)2 * sj + 1] = mode == 3 ? jobs[2 * j + 1] * n_bins + k : jobs[2 * j + 1];
             }
         prefix.resize((size_t)n_sjobs + 1);
-        job_runs.assign((size_t)3 * n_sjobs, 0);
+        job_recs.assign((size_t)n_sjobs, JobRec{0, 0, 0, 0, 0});
         for (int64_t j = 0; j < n_sjobs; ++j) {
             const int p = sjobs[(size_t)2 * j + (swap ? 1 : 0)], q = sjobs[(size_t)2 * j + (swap ? 0 : 1)];  // streamed, lane side
             const int o = orient[(size_t)(mode == 3 ? j / n_bins : j)];
             const StripLayout &sl1 = *LS[o], &sl2 = *LL[o];
             const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
-            job_runs[(size_t)3 * j + 2] = o;
+            JobRec &jr = job_recs[(size_t)j];
+            jr.o = o;
             prefix[(size_t)j] = n_items;
             // strips of q whose grid index lies within `reach` of the strips group p occupies
             const int64_t cnt1 = sl1.h_vbase[(size_t)p + 1] - sl1.h_vbase[(size_t)p], lo1 = sl1.h_slo[(size_t)p];
@@ -3417,8 +3504,10 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             const int64_t s_lo = std::max<int64_t>(lo1 - reach - lo2, 0), s_hi = std::min<int64_t>(lo1 + cnt1 - 1 + reach - lo2, cnt2 - 1);
             if (cnt1 > 0 && s_hi >= s_lo) {
                 const int64_t r0 = sl2.h_vbase[(size_t)q] + s_lo;
-                job_runs[(size_t)3 * j] = (int32_t)s_lo;
-                job_runs[(size_t)3 * j + 1] = (int32_t)(s_hi - s_lo + 1);
+                jr.t_lo = tiles[(size_t)r0];
+                jr.k_off = lo2 - sl2.h_vbase[(size_t)q] - lo1;  // strip index of lane run r2 on the common grid, relative to group p
+                jr.vbase1 = sl1.h_vbase[(size_t)p];
+                jr.n_strips1 = (int32_t)cnt1;
                 n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * ((2 * reach + 1 + MAX_WIN - 1) / MAX_WIN);
             }
         }
@@ -3482,16 +3571,17 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
             if (!L1[o]) continue;
             const StripLayout &a = *L1[o], &b = *L2[o];
             h_tabs[o] = make_tab(a.x, a.y, a.z, a.w, merged ? a.k : nullptr, a.off, a.d_vbase, a.d_slo, a.d_tiles[tile_idx],
-                                 a.d_tile_run[tile_idx], o, a.q, a.q_stride);
+                                 a.d_tile_rec[tile_idx], a.d_grid, o, a.q, a.q_stride);
             h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx],
-                                     b.d_tile_run[tile_idx], o, b.q, b.q_stride);
+                                     b.d_tile_rec[tile_idx], b.d_grid, o, b.q, b.q_stride);
         }
     } else {
-        h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, c1->axis);
-        h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, nullptr, c2->axis);
+        h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, nullptr, c1->axis);
+        h_tabs[3] = make_tab(c2->x, c2->y, c2->z, c2->w, nullptr, c2->off, nullptr, nullptr, nullptr, nullptr, nullptr, c2->axis);
     }
     // the tables of the call, packed into the pinned staging buffer and sent with one copy
-    const size_t n_jobtab = strip_items ? (size_t)5 * n_sjobs : (size_t)2 * n_jobs;  // (p, q) pairs, then (first run, runs, orientation)
+    static_assert(sizeof(JobRec) == 8 * sizeof(int32_t), "JobRec is 32 bytes");
+    const size_t n_jobtab = strip_items ? (size_t)8 * n_sjobs : (size_t)2 * n_jobs;  // JobRec per job, or (p, q) pairs
     size_t off_in = 0;
     auto take = [&](size_t bytes) { const size_t o = off_in; off_in = align16(off_in + bytes); return o; };
     const size_t o_jobs = take(n_jobtab * sizeof(int32_t));
@@ -3504,8 +3594,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     const size_t o_tabs = take(sizeof h_tabs);
     HIP_TRY(ctx->in.reserve(off_in));
     if (strip_items) {
-        memcpy(ctx->in.h + o_jobs, sjobs.data(), sizeof(int32_t) * 2 * n_sjobs);
-        memcpy(ctx->in.h + o_jobs + sizeof(int32_t) * 2 * n_sjobs, job_runs.data(), sizeof(int32_t) * 3 * n_sjobs);
+        memcpy(ctx->in.h + o_jobs, job_recs.data(), sizeof(JobRec) * n_sjobs);
     } else {
         memcpy(ctx->in.h + o_jobs, jobs, sizeof(int32_t) * 2 * n_jobs);
     }
@@ -3554,7 +3643,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         const unsigned bgrid = (unsigned)((n_pot + bwg - 1) / bwg);
         if (strip_items)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(bwg), 0, ctx->stream, ctx->d_tabs.ptr,
-                               ctx->d_jobs.ptr, ctx->d_jobs.ptr + 2 * (size_t)n_sjobs, ctx->d_prefix.ptr, (int)n_sjobs, reach,
+                               reinterpret_cast<const JobRec *>(ctx->d_jobs.ptr), ctx->d_prefix.ptr, (int)n_sjobs, reach,
                                (int)tile, rwin_max, swap ? 1 : 0, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
@@ -3892,7 +3981,9 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         HIP_TRY(hipEventElapsedTime(&cms, ctx->evc0, ctx->evc1));
         stats->count_ms = cms;
         stats->candidate_pairs = cs.cand;
-        stats->evaluated_pairs = (int64_t)ctr[1] * ((cs.run_unweighted ? 1 : 0) + (cs.run_weighted ? 1 : 0));
+        unsigned long long tile_pairs = 0;
+        for (int i = 0; i < EVAL_SLOTS; ++i) tile_pairs += ctr[10 + 8 * (size_t)i];
+        stats->evaluated_pairs = (int64_t)tile_pairs * ((cs.run_unweighted ? 1 : 0) + (cs.run_weighted ? 1 : 0));
         if (cs.band_ran) {  // band kernel: the entries its lanes really walked (both launches of a weighted + counts call)
             unsigned long long ev = 0;
             for (int i = 0; i < EVAL_SLOTS; ++i) ev += ctr[8 + 8 * (size_t)i];
