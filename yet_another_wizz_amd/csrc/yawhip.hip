@@ -40,18 +40,42 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
 #include <system_error>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "yawhip.h"
 #include "yawhip_sort.h"
 
 namespace {
+// YAWHIP_TRACE=1: wall-clock marks of a call's host side, printed to stderr when the call returns (diagnostics; two
+// clock reads per mark when off)
+struct Trace {
+    bool on = getenv("YAWHIP_TRACE") != nullptr;
+    int n = 0;
+    const char *name[32];
+    std::chrono::steady_clock::time_point at[32];
+    void mark(const char *what) {
+        if (on && n < 32) { name[n] = what; at[n++] = std::chrono::steady_clock::now(); }
+    }
+    void flush() {
+        if (on && n > 1) {
+            fprintf(stderr, "[yawhip trace]");
+            for (int i = 1; i < n; ++i)
+                fprintf(stderr, " %s +%.1f", name[i], std::chrono::duration<double, std::micro>(at[i] - at[i - 1]).count());
+            fprintf(stderr, " | total %.1f us\n", std::chrono::duration<double, std::micro>(at[n - 1] - at[0]).count());
+        }
+        n = 0;
+    }
+};
+thread_local Trace g_trace;
+
 
 constexpr int WG = 256;      // threads per workgroup = 4 waves of 64
 constexpr int STAGE = 256;   // streamed objects per LDS stage (one per thread)
@@ -2322,6 +2346,7 @@ struct yawhip_ctx {
     int band_grid_div = 4;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest;
                              // 1, 2, 4 and 8 measure the same at the headline)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
+    int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
     int band_fp32 = 1;       // band kernel on strip layouts of unit vectors: float32 classification + exact float64 for the
                              // guard bands (k_count_band32); 0: every entry in float64 (k_count_band)
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
@@ -2908,6 +2933,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->hist_copies_log2 = (int)value;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "spin_wait")) {
+        ctx->spin_wait = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "band_cap")) {
         if (value != 0 && value != BCAP && value != BCAP_MID && value != B32_CAP && value != B32_CAP_BIG)
             return fail(YAWHIP_ERR_INVALID, "band_cap must be 0 (auto), 192 or 288 (float64 / fine-grid band kernels), %d or %d (float32 band kernel)",
@@ -3215,6 +3244,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                   bool want_counts, bool want_sums, int64_t *job_work, CallState &cs, bool fetch_results = true) {
     cs = CallState{};
     cs.wall0 = std::chrono::steady_clock::now();
+    g_trace.mark("enqueue");
     cs.want_counts = want_counts;
     cs.want_sums = want_sums;
     if (!ctx || !c1 || !c2) return fail(YAWHIP_ERR_INVALID, "yawhip_count_pairs: NULL handle");
@@ -3604,7 +3634,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     memcpy(ctx->in.h + o_rwin, rwin.data(), sizeof(double) * n_bins);
     if (!thr32.empty()) memcpy(ctx->in.h + o_thr32, thr32.data(), sizeof(float) * thr32.size());
     memcpy(ctx->in.h + o_tabs, h_tabs, sizeof h_tabs);
+    g_trace.mark("tables");
     HIP_TRY(hipMemcpyAsync(ctx->in.d, ctx->in.h, off_in, hipMemcpyHostToDevice, ctx->stream));
+    g_trace.mark("h2d");
     ctx->d_jobs.ptr = reinterpret_cast<int32_t *>(ctx->in.d + o_jobs);
     ctx->d_prefix.ptr = reinterpret_cast<int64_t *>(ctx->in.d + o_prefix);
     ctx->d_t.ptr = reinterpret_cast<double *>(ctx->in.d + o_t);
@@ -3628,6 +3660,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
     const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
+    g_trace.mark("memset");
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_pot > 0) {
         if (n_pot >= (1ll << 31))
@@ -3937,6 +3970,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     cs.launches = launches; cs.kernel = kernel; cs.mode = mode;
     cs.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
     cs.band_variant = !band_ran ? 0 : (band32 ? 32 : (band_fine ? 33 : 64));
+    g_trace.mark("launched");
     return YAWHIP_OK;
 }
 
@@ -3960,8 +3994,21 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         }
         return YAWHIP_OK;
     }
+    g_trace.mark("meanwhile");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->spin_wait) {
+        // poll for up to 2 ms (a headline call takes 0.5 ms; the wake-up of a blocked thread costs ~0.01 ms), then block
+        hipError_t qe;
+        const auto spin0 = std::chrono::steady_clock::now();
+        while ((qe = hipStreamQuery(ctx->stream)) == hipErrorNotReady &&
+               std::chrono::steady_clock::now() - spin0 < std::chrono::milliseconds(2))
+            __builtin_ia32_pause();
+        if (qe == hipErrorNotReady) qe = hipStreamSynchronize(ctx->stream);
+        HIP_TRY(qe);
+    } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    g_trace.mark("waited");
     if (!row_index) {
         if (fine_counts) memcpy(fine_counts, ctx->out.h + cs.o_counts, sizeof(int64_t) * (size_t)cs.n_out);
         if (fine_sums) memcpy(fine_sums, ctx->out.h + cs.o_sums, sizeof(double) * (size_t)cs.n_out);
@@ -4027,10 +4074,12 @@ void add_stats(yawhip_stats &total, const yawhip_stats &part, bool side_by_side)
 // One job list on one device, cut in halves as often as count_enqueue asks for (SPLIT_JOBS).
 int run_single(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c2, int32_t n_jobs, const int32_t *jobs,
                int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel, int64_t *fine_counts, double *fine_sums,
-               yawhip_stats *stats) {
+               yawhip_stats *stats, const std::function<void()> *meanwhile = nullptr) {
+    // meanwhile: host work of the caller that does not need the result, done while the device counts (once)
     CallState cs;
     int rc = count_enqueue(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_counts != nullptr, fine_sums != nullptr,
                            nullptr, cs);
+    if (meanwhile && (rc == YAWHIP_OK || rc == SPLIT_JOBS)) (*meanwhile)();
     if (rc == YAWHIP_OK) return count_finish(ctx, cs, fine_counts, fine_sums, stats);
     if (rc != SPLIT_JOBS) return rc;
     const int32_t half = n_jobs / 2;
@@ -4326,10 +4375,10 @@ int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const ya
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_comb, d_comb, sizeof(double) * (size_t)n_comb, hipMemcpyDeviceToHost, ctx->stream));
             }
+            // (the result tensor is cleared while the device counts: 1 MB, 0.04 ms at the headline)
+            memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
             rc = count_finish(ctx, cs, nullptr, nullptr, stats);  // waits for the stream
             if (rc != YAWHIP_OK) return rc;
-            const int64_t P = c1->n_patches;
-            memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
             if (cs.pending)
                 for (int k = 0; k < n_bins; ++k)
                     for (int64_t j = 0; j < n_jobs; ++j) {
@@ -4347,21 +4396,53 @@ int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const ya
     std::unique_ptr<double[]> fine_s(weighted ? new (std::nothrow) double[n_fine] : nullptr);
     std::unique_ptr<int64_t[]> fine_c(weighted ? nullptr : new (std::nothrow) int64_t[n_fine]);
     if (!fine_s && !fine_c) return fail(YAWHIP_ERR_OOM, "yawhip_count_pairs_dense: out of host memory");
-    const int rc = yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_c.get(), fine_s.get(), stats);
-    if (rc != YAWHIP_OK) return rc;
-    // Host epilogue, O(jobs x B x E), of PatchLinkage.count_pairs (reference src/yaw/correlation/measurements.py:354-364 with
-    // src/yaw/catalog/trees.py:358-362,134-160 applied per job): separation weights, per-scale sums of the fine bins, halving
-    // of the doubly counted diagonal of an autocorrelation, scatter into [scale][bin][patch i][patch j]; unlinked slots are 0.
-    memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
-    std::vector<double> scaled((size_t)nf);
     for (int64_t j = 0; j < n_jobs; ++j)
         if (jobs[2 * j] < 0 || jobs[2 * j] >= P || jobs[2 * j + 1] < 0 || jobs[2 * j + 1] >= P)
             return fail(YAWHIP_ERR_INVALID, "job %lld has a patch id outside [0,%lld)", (long long)j, (long long)P);
+    // Host epilogue, O(jobs x B x E), of PatchLinkage.count_pairs (reference src/yaw/correlation/measurements.py:354-364 with
+    // src/yaw/catalog/trees.py:358-362,134-160 applied per job): separation weights, per-scale sums of the fine bins, halving
+    // of the doubly counted diagonal of an autocorrelation, scatter into [scale][bin][patch i][patch j]; unlinked slots are 0.
+    // The tensor is cleared while the device counts (1 MB, 0.04 ms at the headline) when the call runs on one device.
+    bool cleared = false;
+    const std::function<void()> clear = [&]() {
+        memset(dense, 0, sizeof(double) * (size_t)n_scales * (size_t)n_bins * (size_t)(P * P));
+        cleared = true;
+    };
+    const int rc = ctx->peers.empty() ? run_single(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_c.get(), fine_s.get(), stats, &clear)
+                                      : yawhip_count_pairs(ctx, c1, c2, n_jobs, jobs, n_bins, n_edges, t, kernel, fine_c.get(), fine_s.get(), stats);
+    if (rc != YAWHIP_OK) return rc;
+    g_trace.mark("finished");
+    if (!cleared) clear();
+    std::vector<double> scaled((size_t)nf);
+    std::vector<int64_t> cell((size_t)n_jobs);  // p * P + q and the factor of every job, once
+    std::vector<double> half((size_t)n_jobs);
+    for (int64_t j = 0; j < n_jobs; ++j) {
+        cell[(size_t)j] = (int64_t)jobs[2 * j] * P + jobs[2 * j + 1];
+        half[(size_t)j] = (halve_diagonal && jobs[2 * j] == jobs[2 * j + 1]) ? 0.5 : 1.0;
+    }
     for (int k = 0; k < n_bins; ++k) {  // bin by bin: the scattered writes of one pass stay inside S slices of [P, P]
         const double *wk = fine_factors ? fine_factors + (size_t)k * nf : nullptr;
+        if (nf == 1) {  // one value per (job, bin), the usual call: numpy's sum of one element is the element
+            for (int s_ = 0; s_ < n_scales; ++s_) {
+                const bool take = slices[2 * ((int64_t)k * n_scales + s_) + 1] > slices[2 * ((int64_t)k * n_scales + s_)];
+                if (!take) continue;  // (cleared above)
+                double *slice = dense + ((size_t)s_ * n_bins + k) * (size_t)(P * P);
+                const double w0 = wk ? wk[0] : 1.0;
+                if (weighted)
+                    for (int64_t j = 0; j < n_jobs; ++j) {
+                        const double v = fine_s[(size_t)j * row + (size_t)k];
+                        slice[cell[(size_t)j]] = (wk ? v * w0 : v) * half[(size_t)j];
+                    }
+                else
+                    for (int64_t j = 0; j < n_jobs; ++j) {
+                        const double v = (double)fine_c[(size_t)j * row + (size_t)k];
+                        slice[cell[(size_t)j]] = (wk ? v * w0 : v) * half[(size_t)j];
+                    }
+            }
+            continue;
+        }
         for (int64_t j = 0; j < n_jobs; ++j) {
-            const int64_t p = jobs[2 * j], q = jobs[2 * j + 1];
-            const double f = (halve_diagonal && p == q) ? 0.5 : 1.0;
+            const double f = half[(size_t)j];
             const size_t at = (size_t)j * row + (size_t)k * nf;
             const double *fk = weighted ? fine_s.get() + at : scaled.data();
             if (!weighted)
@@ -4373,10 +4454,12 @@ int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const ya
             for (int s_ = 0; s_ < n_scales; ++s_) {
                 const int lo = slices[2 * ((int64_t)k * n_scales + s_)], hi = slices[2 * ((int64_t)k * n_scales + s_) + 1];
                 const double acc = hi > lo ? numpy_sum(fk + lo, hi - lo) : 0.0;
-                dense[(((size_t)s_ * n_bins + k) * P + p) * P + q] = acc * f;
+                dense[((size_t)s_ * n_bins + k) * (size_t)(P * P) + (size_t)cell[(size_t)j]] = acc * f;
             }
         }
     }
+    g_trace.mark("scattered");
+    g_trace.flush();
     return YAWHIP_OK;
 }
 
