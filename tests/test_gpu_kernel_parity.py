@@ -720,8 +720,9 @@ def test_float32_guard_bands_are_decided_exactly(ctx, theta_deg, grid):
             assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == 1
             assert np.array_equal(counts, exp), fp32
             # the engineered partners sit inside the guard bands: the exact predicate must have been called on for many of them
-            # (a fine grid over tens of degrees is not log-spaced in chord^2 any more -- sin -- and stays on the float64 kernel)
-            want = 64 if (not fp32 or (grid == "fine" and theta_deg > 10.0)) else (33 if grid == "fine" else 32)
+            # (a fine grid over tens of degrees is not exactly log-spaced in chord^2 any more -- sin --, but the model only has
+            # to name the nearest edge: it stays on the fine-grid kernel)
+            want = 64 if not fp32 else (33 if grid == "fine" else 32)
             assert st.band_variant == want
             assert (st.exact_reevaluations > n // 20) if want != 64 else (st.exact_reevaluations == 0)
     finally:

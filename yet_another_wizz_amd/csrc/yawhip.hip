@@ -173,7 +173,7 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #define YAW_B32_UNROLL 1  // entries per trip of the walk loop: 1, 2 and 4 measure the same (0.362 / 0.366 / 0.374 ms at the headline)
 #endif
 #ifndef YAW_B32_WAVES_W
-#define YAW_B32_WAVES_W 1  // waves per SIMD the weighted one-annulus variants are compiled for (1: the compiler's choice)
+#define YAW_B32_WAVES_W 5  // waves per SIMD the weighted one-annulus variants are compiled for (96 VGPRs; the compiler took 97 by itself: 4 waves, 0.57 against 0.51 ms)
 #endif
 #ifndef YAW_B32_WAVES
 #define YAW_B32_WAVES 1  // > 1: waves per SIMD every variant is compiled for (experiments). Default: 7 for the plain count (72 VGPRs
@@ -1514,15 +1514,30 @@ __host__ __device__ inline size_t band32_lds(bool weighted, int cap, int nslots,
 }
 
 // The exact predicate of the parity contract on the float64 columns, for an evaluation the float32 classes left undecided
-// (rare: kept out of line so that its addresses and temporaries do not live in the walk loop's registers).
-__device__ __attribute__((noinline)) double band32_exact_s(gf64p lx, gf64p ly, gf64p lz, int64_t li, gf64p sx, gf64p sy, gf64p sz,
-                                                           int64_t gi, unsigned long long *__restrict__ counters) {
+// (rare: kept out of line so that its addresses and temporaries do not live in the walk loop's registers). The float64
+// thresholds the caller will compare with travel in the same round trip as the coordinates: an undecided evaluation stalls
+// its wave for ONE memory latency (coordinates, then thresholds one after the other, were two to four; at 51 edges per bin
+// one trip in nine of the walk meets an undecided evaluation and the stalls were a third of the kernel's time).
+template <int NT>
+struct ExactEval {
+    double s;        // ((dx*dx + dy*dy) + dz*dz), rounded product by product
+    double th[NT];   // tk[0 .. NT)
+};
+template <int NT>
+__device__ __attribute__((noinline)) ExactEval<NT> band32_exact(gf64p lx, gf64p ly, gf64p lz, int64_t li, gf64p sx, gf64p sy, gf64p sz,
+                                                               int64_t gi, const double *__restrict__ tk,
+                                                               unsigned long long *__restrict__ counters) {
     atomicAdd(counters, 1ull);  // statistics: evaluations decided by the exact predicate (the caller passes one of EVAL_SLOTS
                                 // counters: tens of thousands of adds per launch on ONE address cost 0.4 ms at the headline)
-    const double dx = lx[li] - sx[gi], dy = ly[li] - sy[gi], dz = lz[li] - sz[gi];
+    ExactEval<NT> r;
+    const double ax = lx[li], ay = ly[li], az = lz[li], bx = sx[gi], by = sy[gi], bz = sz[gi];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) r.th[e] = tk[e];
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
     const double xx = dx * dx, yy = dy * dy, zz = dz * dz;
     const double sxy = xx + yy;
-    return sxy + zz;
+    r.s = sxy + zz;
+    return r;
 }
 
 #ifndef YAW_B32_CAP
@@ -1856,17 +1871,19 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx, counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
-                            const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * NE;
+                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx,
+                                                                      t + (size_t)(MERGED ? kb[r] : kfix) * NE,
+                                                                      counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
+                            const double sd = ev.s;
                             if constexpr (NE == 2) {
-                                const bool in = sd > tk[0] && sd <= tk[1];
+                                const bool in = sd > ev.th[0] && sd <= ev.th[1];
                                 if constexpr (WEIGHTED) acc[r][0] += in ? ew : 0.0;
                                 else cnt[r][0] += in ? 1u : 0u;
                             } else {
 #pragma unroll
                                 for (int e = 0; e < NE; ++e) {
                                     const bool open = !(s32[r] < th[r][2 * e]) && s32[r] <= th[r][2 * e + 1];  // this edge was left undecided
-                                    const bool le = open && sd <= tk[e];
+                                    const bool le = open && sd <= ev.th[e];
                                     if constexpr (WEIGHTED) acc[r][e] += le ? ew : 0.0;
                                     else cnt[r][e] += le ? 1u : 0u;
                                 }
@@ -1912,16 +1929,18 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 // Band kernel for FINE radial grids (separation weights: `resolution` + 1 log-spaced edges per redshift bin,
 // reference src/yaw/catalog/trees.py:107-117,358-360). Items, staging, band search and the float32 distance are
 // k_count_band32's; what differs is how an evaluation finds its fine bin among ~50:
-//   * the edges of a bin are log-spaced, so f = (log2 s32 - log2 t_0) * m puts edge j at f = j (the host checks the
-//     table against this model and passes its worst deviation): the fine bin is floor(f) -- one v_log_f32, one fma, one
-//     floor instead of a six-step binary search through LDS;
-//   * the guess is CERTAIN when the fractional part of f keeps eps(s32) = e0 + e1 / sqrt(s32) away from 0 and 1; eps covers
-//     the model's deviation, the error of the hardware logarithm and the float32 guard g(t) of k_count_band32;
-//   * otherwise (a few 1e-3 of the evaluations) the lane reads the float32 bounds {t_j - g, t_j + g} of the NEAREST edge
-//     j = round(f) from an LDS table and decides between bins j - 1 and j; inside the guard band the exact float64
-//     predicate on the float64 columns decides, against the host's float64 thresholds.
+//   * the edges of a bin are log-spaced, so f = (log2 s32 - log2 t_0) * m puts edge j near f = j: j = round(f), clamped to
+//     the table, is the NEAREST edge -- one v_log_f32, one fma, one round instead of a six-step binary search;
+//   * the lane reads the float32 bounds {t_j - g, t_j + g} of that edge (g: the guard of k_count_band32) from an LDS table:
+//     s32 below the lower bound is in fine bin j - 1, above the upper bound in bin j; the host admits a table only if f is
+//     off by less than half a bin everywhere (build_fine32), so the edges on the other side of s32 need no look;
+//   * inside the guard band (~1e-3 of the evaluations in range) the exact float64 predicate on the float64 columns decides,
+//     against the host's float64 thresholds.
 // Hits go to an LDS histogram [bin][fine bin] with one atomic per evaluation (a miss adds to the lane's dummy cell).
-// Rows of the float32 table (fine32): {m, a = m log2 t_0, e0, e1}, then {t_j - g, t_j + g} per edge.
+// Rows of the float32 table (fine32): {m, a = m log2 t_0, 0, 0}, then {t_j - g, t_j + g} per edge.
+// (The first version guessed the bin as floor(f) and was certain only if f kept a distance eps(s32) = e0 + e1 / sqrt(s32)
+// from the grid, with a second look at the table otherwise: 32 instruction slots per evaluation against 18 now, and a
+// third of the walk's trips took the second look. 2.09 -> 1.25 ms then, -> see DESIGN.md for this one.)
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int fine32_width(int n_edges) { return 4 + 2 * n_edges; }
 __host__ __device__ inline size_t band32_fine_lds(bool weighted, int cap, int nslots, int rows, int n_edges) {
@@ -2032,13 +2051,25 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                 if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
             }
         };
-        // row of every lane object in the float32 table, its model parameters in registers
-        int trow[R];
-        float pm[R], pa[R], pe0[R], pe1[R];
+        // row of every lane object in the float32 table: model parameters in registers, LDS addresses of its edge bounds
+        // and of its row of the histogram
+        float pm[R], pa[R];
+        unsigned a_edges[R], a_rowh[R];
+        const float nf_f = (float)nf;
+        const unsigned a_stab = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(stab);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            trow[r] = (UNI ? 0 : (MERGED ? kb[r] : kfix)) * tw;
-            pm[r] = stab[trow[r]]; pa[r] = stab[trow[r] + 1]; pe0[r] = stab[trow[r] + 2]; pe1[r] = stab[trow[r] + 3];
+            const int trow = (UNI ? 0 : (MERGED ? kb[r] : kfix)) * tw;
+            pm[r] = stab[trow]; pa[r] = stab[trow + 1];
+            a_edges[r] = a_stab + (unsigned)(trow + 4) * 4u;
+            a_rowh[r] = a_hist + ((unsigned)(kb[r] * nf) << HB);
+        }
+        f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
+        if constexpr (R >= 2) {
+#pragma unroll
+            for (int h = 0; h < R / 2; ++h) {
+                ax2[h] = f32x2{ax[2 * h], ax[2 * h + 1]}; ay2[h] = f32x2{ay[2 * h], ay[2 * h + 1]}; az2[h] = f32x2{az[2 * h], az[2 * h + 1]};
+            }
         }
 
         for (int win = 0; win < it.nwin; ++win) {
@@ -2083,63 +2114,99 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
 
             unsigned cur = a_stage + ((unsigned)lo << 2);
             const unsigned last = a_stage + ((unsigned)n << 2);
+            // The walk is a chain of LDS round trips (entry -> nearest edge -> its bounds -> histogram): the next entry is
+            // fetched while this one is classified, and the edge bounds of all lane objects are fetched together.
+            struct Entry { float x, y, z; double w; unsigned at; };
+            auto fetch = [&](unsigned at) {
+                Entry e;
+                e.at = at < last ? at : last;
+                e.x = *(const __attribute__((address_space(3))) float *)(size_t)e.at;
+                e.y = *(const __attribute__((address_space(3))) float *)(size_t)(e.at + COLB);
+                e.z = *(const __attribute__((address_space(3))) float *)(size_t)(e.at + 2 * COLB);
+                e.w = WEIGHTED ? lds_f64(((e.at - a_stage) << 1) + a_sw) : 1.0;
+                return e;
+            };
+            unsigned pend[R];  // cells of the previous entry's hits (unweighted)
+#pragma unroll
+            for (int r = 0; r < R; ++r) pend[r] = a_dummy;
+            Entry nxt = fetch(cur);
+            // (consumed here, so that the compiler's wait-count bookkeeping enters the loop with nothing of the prologue pending:
+            // a wait at the loop header has to satisfy every incoming edge, and "the reads just issued" of the prologue would
+            // turn it into a full drain -- of the previous trip's histogram updates, every trip)
+            if constexpr (WEIGHTED) asm volatile("" :: "v"(nxt.x), "v"(nxt.y), "v"(nxt.z), "v"(nxt.w));
+            else asm volatile("" :: "v"(nxt.x), "v"(nxt.y), "v"(nxt.z));
             for (int s = 0; s < steps; ++s) {
-                const unsigned a16 = cur < last ? cur : last;
+                const Entry en = nxt;
                 cur += 4;
-                const float ex = *(const __attribute__((address_space(3))) float *)(size_t)a16;
-                const float ey = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + COLB);
-                const float ez = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + 2 * COLB);
-                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) << 1) + a_sw) : 1.0;
-                float s32[R], f[R];
-                bool med[R];
-                bool any_med = false;
+                nxt = fetch(cur);  // (past the longest band: an entry beyond every band, or the sentinel -- never used)
+                const unsigned a16 = en.at;
+                const float ex = en.x, ey = en.y, ez = en.z;
+                const double ew = en.w;
+                float s32[R];
+                if constexpr (R >= 2) {
+#pragma unroll
+                    for (int h = 0; h < R / 2; ++h) {
+                        const f32x2 dx = ax2[h] - ex, dy = ay2[h] - ey, dz = az2[h] - ez;
+                        const f32x2 sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                        s32[2 * h] = sq.x; s32[2 * h + 1] = sq.y;
+                    }
+                } else {
+                    const float dx = ax[0] - ex, dy = ay[0] - ey, dz = az[0] - ez;
+                    s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                }
+                int jj[R];
+                bool unc[R];
+                bool any_unc = false;
+                f32x2 tb[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float dx = ax[r] - ex, dy = ay[r] - ey, dz = az[r] - ez;
-                    s32[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    f[r] = __builtin_fmaf(__builtin_amdgcn_logf(s32[r]), pm[r], -pa[r]);  // edge j of the object's bin sits at f = j
-                    const float fl = __builtin_floorf(f[r]);
-                    const float eps = __builtin_fmaf(__builtin_amdgcn_rsqf(s32[r]), pe1[r], pe0[r]);
-                    const bool cert = __builtin_fabsf((f[r] - fl) - 0.5f) < 0.5f - eps;  // (false for s32 = 0: f = -inf, eps = inf)
-                    const int g = (int)fl;
-                    const bool fast = cert & ((unsigned)g < (unsigned)nf);
-                    med[r] = !cert & (f[r] > -1.0f) & (f[r] < (float)(nf + 1));
-                    any_med |= med[r];
-                    const unsigned cell = a_hist + ((unsigned)(kb[r] * nf + g) << HB);
+                    // nearest edge of the object's grid (s32 = 0: f = -inf -> edge 0) and its float32 bounds
+                    const float fr = __builtin_rintf(__builtin_fmaf(__builtin_amdgcn_logf(s32[r]), pm[r], -pa[r]));
+                    jj[r] = (int)__builtin_amdgcn_fmed3f(fr, 0.0f, nf_f);
+                    tb[r] = *(const __attribute__((address_space(3))) f32x2 *)(size_t)(a_edges[r] + ((unsigned)jj[r] << 3));
+                }
+                if constexpr (!WEIGHTED) {
+                    // the histogram updates of the PREVIOUS entry go out behind this entry's reads: by the time the loop comes
+                    // round to anything that waits for the LDS, they have long been absorbed
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)pend[r], 1u,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int j = jj[r];
+                    const bool below = s32[r] < tb[r].x;  // the side of the edge s32 lies on
+                    const int bin = j - (below ? 1 : 0);
+                    unc[r] = !below && !(s32[r] > tb[r].y);  // inside the guard band of edge j
+                    any_unc |= unc[r];
+                    const bool hit = ((unsigned)bin < (unsigned)nf) & !unc[r];
+                    const unsigned cell = a_rowh[r] + ((unsigned)bin << HB);
                     if constexpr (WEIGHTED) {
-                        if (fast)
+                        if (hit)
                             (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * ew,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)(fast ? cell : a_dummy), 1u,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pend[r] = hit ? cell : a_dummy;  // a miss adds to the lane's dummy cell
                     }
                 }
 #if defined(YAW_FINE_DIAG) && YAW_FINE_DIAG == 6
-                any_med = false;  // diagnostics: no second look at the evaluations near an edge (wrong counts)
+                any_unc = false;  // diagnostics: no exact re-evaluation (wrong counts)
 #endif
-                if (__builtin_amdgcn_ballot_w64(any_med) != 0ull) {
-                    // near an edge of the fine grid: the float32 bounds of that edge decide, the exact predicate inside them
+                if (__builtin_amdgcn_ballot_w64(any_unc) != 0ull) {
+                    // the exact float64 predicate on the float64 columns decides, against the host's float64 thresholds (rare)
                     const unsigned eidx = (a16 - a_stage) >> 2;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
-                        if (med[r]) {
-                            int j = (int)__builtin_rintf(f[r]);
-                            j = j < 0 ? 0 : (j > nf ? nf : j);
-                            const float tm = stab[trow[r] + 4 + 2 * j], tp = stab[trow[r] + 5 + 2 * j];
-                            int bin = s32[r] < tm ? j - 1 : j;
-                            if (!(s32[r] < tm) && !(s32[r] > tp)) {  // inside the guard band of edge j
-                                bin = -1;
-                                if (eidx < (unsigned)n && r < n_own) {
-                                    const double sd = band32_exact_s(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx, counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
-                                    const double *tk = t + (size_t)(MERGED ? kb[r] : kfix) * n_edges;
-                                    bin = sd <= tk[j] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
-                                    if (bin >= 0 && !(sd > tk[bin])) bin = -1;        // (degenerate tables: equal edges)
-                                    if (bin < nf && bin >= 0 && !(sd <= tk[bin + 1])) bin = -1;
-                                }
-                            }
+                        if (unc[r] && eidx < (unsigned)n && r < n_own) {
+                            const int j = jj[r];
+                            // (the admission rule of build_fine32 leaves edge j as the only one s can be confused with)
+                            const ExactEval<1> ev = band32_exact<1>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx,
+                                                                    t + (size_t)(MERGED ? kb[r] : kfix) * n_edges + j,
+                                                                    counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
+                            const int bin = ev.s <= ev.th[0] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
                             if ((unsigned)bin < (unsigned)nf) {
-                                const unsigned cell = a_hist + ((unsigned)(kb[r] * nf + bin) << HB);
+                                const unsigned cell = a_rowh[r] + ((unsigned)bin << HB);
                                 if constexpr (WEIGHTED)
                                     (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw[r] * ew,
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2150,6 +2217,12 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                         }
                     }
                 }
+            }
+            if constexpr (!WEIGHTED) {  // the last entry's updates
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)pend[r], 1u,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (!WEIGHTED && (stage_no & flush_mask) == flush_mask) flush_counts();
         }
@@ -3222,11 +3295,12 @@ std::vector<float> build_fine32(const double *t, int n_bins, int n_edges) {
         // error of the device's f: hardware log2 (1 ulp of a result below 64), float32 images of m and a, the fma
         const double dev_f = m * (1e-5 + 6e-8 * 64.0) + 2.0 * 6e-8 * std::fabs(a) + 4e-5 + 6e-8 * (nf + 2);
         const double per_s = 1.05 * m / std::log(2.0);  // d f / (d s / s), with room for the second order
-        const double e0 = dev + dev_f + per_s * (5e-7 + 1e-12 / tk[0]);
-        const double e1 = per_s * 1.1 * BAND32_GUARD_SQRT;  // x 1.1: eps is taken at s32, up to a fifth of a bin away from the edge
-        if (dev > 0.05 || e0 + e1 / std::sqrt(tk[0]) > 0.2) return {};
+        // Admission: an s32 between the guard bands of edges j and j + 1 must round to one of the two, i.e. f may be off by
+        // less than half a bin: the model's deviation at the edges, the device's arithmetic, and the guard (widest,
+        // relative to t, at the first edge).
+        if (dev + dev_f + per_s * guard(tk[0]) / tk[0] > 0.45) return {};
         float *row = &out[(size_t)k * tw];
-        row[0] = (float)m; row[1] = (float)a; row[2] = up(e0); row[3] = up(e1);
+        row[0] = (float)m; row[1] = (float)a; row[2] = 0.f; row[3] = 0.f;
         for (int j = 0; j <= nf; ++j) {
             const double g = guard(tk[j]);
             row[4 + 2 * j] = down(tk[j] - g);
