@@ -72,7 +72,7 @@ typedef struct yawhip_stats {
                                   and were decided by the exact float64 predicate (ABI >= 4)                  */
     int32_t band_variant;      /* which band kernel ran (ABI >= 4): 0 none, 64 every entry in float64, 32 float32 classes +
                                   exact guard bands, 33 the same for fine log-spaced radial grids             */
-    int32_t reserved_;
+    int32_t merged_triples;       /* 1: the float32 band kernel streamed merged triple runs (one window per item), else 0 */
 } yawhip_stats;
 
 const char *yawhip_last_error(void);

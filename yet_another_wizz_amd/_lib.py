@@ -64,7 +64,7 @@ class _Stats(ctypes.Structure):
         ("n_orientations", ctypes.c_int32),
         ("exact_reevaluations", ctypes.c_int64),
         ("band_variant", ctypes.c_int32),
-        ("reserved_", ctypes.c_int32),
+        ("merged_triples", ctypes.c_int32),
     ]
 
 
@@ -83,7 +83,7 @@ class CountStats:
     n_orientations: int = 0
     exact_reevaluations: int = 0
     band_variant: int = 0
-    reserved_: int = 0
+    merged_triples: int = 0
 
 
 _dp = ctypes.POINTER(ctypes.c_double)

@@ -189,6 +189,7 @@ struct DevTab {
     const struct TileRec *tile_rec;  // strip layouts: first object, length and run of every lane tile
     const struct RunGrid *grid;      // strip layouts: per-run index along the sort axis (item builder)
     gf32p qx, qy, qz;          // strip layouts: float32 images of the columns (k_count_band32)
+    gi32p idx;                 // merged triple runs (streamed side): index of an entry in the layout's own order, else null
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
@@ -225,7 +226,8 @@ __device__ __forceinline__ int run_cell(double key, double first, double inv) {
     return f >= (double)RUN_GRID ? RUN_GRID - 1 : (f >= 1.0 ? (int)f : 0);
 }
 // one thread per (run, cell boundary): g[c] by bisection with the predicate cell(key) < c
-__global__ __launch_bounds__(256) void k_run_grid(int64_t n_runs, const int64_t *__restrict__ off, const double *__restrict__ key,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_run_grid(int64_t n_runs, const int64_t *__restrict__ off, const KeyT *__restrict__ key,
                                                   RunGrid *__restrict__ grid) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t r = i / (RUN_GRID + 1);
@@ -234,18 +236,71 @@ __global__ __launch_bounds__(256) void k_run_grid(int64_t n_runs, const int64_t 
     const int64_t b0 = off[r], b1 = off[r + 1];
     double inv = 0.0, first = 0.0;
     if (b1 > b0) {
-        first = key[b0];
-        const double span = key[b1 - 1] - first;
+        first = (double)key[b0];
+        const double span = (double)key[b1 - 1] - first;
         inv = span > 0.0 ? (double)RUN_GRID / span : 0.0;
         if (!(inv < 1e300)) inv = 0.0;  // a denormal span: one cell
     }
     int64_t l = b0, h = b1;
     while (l < h) {
         const int64_t m = (l + h) >> 1;
-        if (run_cell(key[m], first, inv) < c) l = m + 1; else h = m;
+        if (run_cell((double)key[m], first, inv) < c) l = m + 1; else h = m;
     }
     grid[r].g[c] = (uint32_t)(l - b0);
     if (c == 0) { grid[r].inv = inv; grid[r].g[RUN_GRID + 1] = 0; }
+}
+
+// Merged triple runs of a strip layout (streamed side of the float32 band kernels). With a grid as wide as the largest
+// separation the partners of a lane tile in strip c are the strips c - 1, c, c + 1 of the other patch: three windows, three
+// band searches and three walks per item, each walk as long as the longest of 64 short bands. The triple run T(group, c)
+// holds the objects of those three strips MERGED along u (float32 images, weights, and the index of every entry in the
+// layout's own order for the exact re-evaluation): one window, one search, one walk whose trip count is the longest of 64
+// bands three times as long -- relatively more even. Every object is a member of three triples: 36 bytes of float32 images
+// per object more (+ 4 for the index, + 24 with weights). c runs over [first strip - 1, last strip + 1] of the group.
+// One thread per entry: its place in each of its three triples is its rank among the members (ties: lower run first).
+__global__ __launch_bounds__(256) void k_merge_triples(int64_t n, int64_t n_runs, const int64_t *__restrict__ off,
+                                                       const int32_t *__restrict__ run_group, const int64_t *__restrict__ vbase,
+                                                       const int64_t *__restrict__ off3, const double *__restrict__ key,
+                                                       const float *__restrict__ q, int64_t q_stride, const double *__restrict__ w,
+                                                       float *__restrict__ q3, int64_t q3_stride, double *__restrict__ w3,
+                                                       int32_t *__restrict__ idx3) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t lo = 0, hi = n_runs;  // run of the entry: the largest r with off[r] <= i
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t r = lo;
+    const int64_t g = run_group[r], g_lo = vbase[g], g_hi = vbase[g + 1];
+    const double ki = key[i];
+    const float fx = q[i], fy = q[q_stride + i], fz = q[2 * q_stride + i];
+    const double wi = w ? w[i] : 0.0;
+    // entries of the group's runs r - 2 .. r + 2 in front of this one
+    int64_t before[5];
+#pragma unroll
+    for (int d = -2; d <= 2; ++d) {
+        const int64_t m = r + d;
+        int64_t cnt = 0;
+        if (d == 0) {
+            cnt = i - off[r];
+        } else if (m >= g_lo && m < g_hi) {
+            int64_t l = off[m], h = off[m + 1];
+            const int64_t base = l;
+            if (d < 0) { while (l < h) { const int64_t mid = (l + h) >> 1; if (key[mid] <= ki) l = mid + 1; else h = mid; } }
+            else       { while (l < h) { const int64_t mid = (l + h) >> 1; if (key[mid] < ki) l = mid + 1; else h = mid; } }
+            cnt = l - base;
+        }
+        before[d + 2] = cnt;
+    }
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {  // triple centred on run r + d: members r + d - 1, r + d, r + d + 1
+        const int64_t t = r + d + 1 + 2 * g;
+        const int64_t dst = off3[t] + before[d + 1] + before[d + 2] + before[d + 3];
+        q3[dst] = fx; q3[q3_stride + dst] = fy; q3[2 * q3_stride + dst] = fz;
+        idx3[dst] = (int32_t)i;
+        if (w3) w3[dst] = wi;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,9 +417,13 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items(CatView c1, CatView c2
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *__restrict__ tabs, const JobRec *__restrict__ jobs,
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
-                                                            int tile, double rwin, int swap, int64_t n_pot,
+                                                            int tile, double rwin, int swap, int triple, int64_t n_pot,
                                                             Item *__restrict__ items, unsigned long long *__restrict__ counters,
                                                             unsigned char *__restrict__ kept) {
+    // triple: the streamed side consists of merged triple runs (k_merge_triples) -- the host passes reach = 0 (one partner
+    // run per lane tile: the triple centred on its strip) and the triples' offsets and grid index in the streamed table; their
+    // sort key exists as float32 image only, so the window is widened by the rounding of a key (the count kernel searches
+    // its bands in float32 with a margin of its own).
     const int64_t pot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     Item it{};
@@ -395,7 +454,9 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const int o = jr.o;  // orientation of the job: which pair of layouts it runs on
         // swap: the lane tiles come from the first catalogue of the job (the binned one), the windows from the second
         const DevTab &c1 = tabs[swap ? 3 + o : o], &c2 = tabs[swap ? o : 3 + o];
-        const gf64p key1 = tab_key(c1), key2 = tab_key(c2);
+        const gf64p key1d = tab_key(c1), key2 = tab_key(c2);
+        const gf32p key1f = c1.axis == 0 ? c1.qx : (c1.axis == 1 ? c1.qy : c1.qz);
+        auto key1 = [&](int64_t i) { return triple ? (double)key1f[i] : key1d[i]; };
         // potential items of a job in the order (lane tile, group of neighbour offsets). One item carries up to MAX_WIN
         // neighbouring strips of the streamed group (all 2 * reach + 1 = 3 of them when the grid is as wide as the
         // largest separation): the lane tile is loaded once and its histogram flushed once for all of them.
@@ -406,7 +467,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const int g = (int)(local32 - tl * (uint32_t)ng);
         const TileRec tr = c2.tile_rec[jr.t_lo + tl];
         const int64_t r2 = tr.run, a0 = tr.a0, a1 = a0 + tr.na;
-        const double wlo = key2[a0] - rwin, whi = key2[a1 - 1] + rwin;
+        const double kpad = triple ? 1.2e-7 : 0.0;  // float32 rounding of a streamed key (|u| <= 1: 2^-24)
+        const double wlo = key2[a0] - rwin - kpad, whi = key2[a1 - 1] + rwin + kpad;
         it.a0 = a0; it.na = tr.na; it.nwin = 0;
         it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
         // The windows of the (up to) three partner runs are searched in lockstep: three independent chains of loads per
@@ -429,7 +491,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
             // (loads under their condition: the texture path is what this kernel is bound by, and it charges the lanes of a
             // load that are switched on; a wave whose tiles face no live run skips them altogether)
             double kfirst = 0.0, klast = 0.0;
-            if (some) { kfirst = key1[b0]; klast = key1[b1 - 1]; }
+            if (some) { kfirst = key1(b0); klast = key1(b1 - 1); }
             const bool live = some && !(klast < wlo || kfirst > whi);
             // the run's index along the sort axis narrows both searches to one cell (RunGrid)
             uint32_t l0 = 0, l1 = 0, u0 = 0, u1 = 0;
@@ -451,8 +513,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
                 ml[j] = sl[j] + ((sh[j] - sl[j]) >> 1);
                 mu[j] = ul[j] + ((uh[j] - ul[j]) >> 1);
                 kl[j] = ku[j] = 0.0;
-                if (sl[j] < sh[j]) kl[j] = key1[wb[j] + ml[j]];
-                if (ul[j] < uh[j]) ku[j] = key1[wb[j] + mu[j]];
+                if (sl[j] < sh[j]) kl[j] = key1(wb[j] + ml[j]);
+                if (ul[j] < uh[j]) ku[j] = key1(wb[j] + mu[j]);
             }
 #pragma unroll
             for (int j = 0; j < MAX_WIN; ++j) {  // ... and consumed after one wait
@@ -1871,7 +1933,8 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, cb[c] + eidx,
+                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z,
+                                                                      cs.idx ? (int64_t)cs.idx[cb[c] + eidx] : cb[c] + (int64_t)eidx,
                                                                       t + (size_t)(MERGED ? kb[r] : kfix) * NE,
                                                                       counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
                             const double sd = ev.s;
@@ -2201,7 +2264,8 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                         if (unc[r] && eidx < (unsigned)n && r < n_own) {
                             const int j = jj[r];
                             // (the admission rule of build_fine32 leaves edge j as the only one s can be confused with)
-                            const ExactEval<1> ev = band32_exact<1>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z, b0 + st0 + eidx,
+                            const ExactEval<1> ev = band32_exact<1>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z,
+                                                                    cs.idx ? (int64_t)cs.idx[b0 + st0 + eidx] : b0 + st0 + (int64_t)eidx,
                                                                     t + (size_t)(MERGED ? kb[r] : kfix) * n_edges + j,
                                                                     counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
                             const int bin = ev.s <= ev.th[0] ? j - 1 : j;  // t[bin] < s <= t[bin + 1]
@@ -2346,9 +2410,9 @@ __global__ void k_counts_to_double(const unsigned long long *__restrict__ in, do
 
 inline DevTab make_tab(const double *x, const double *y, const double *z, const double *w, const int32_t *k, const int64_t *off,
                        const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const TileRec *tile_rec, const RunGrid *grid,
-                       int axis, const float *q = nullptr, int64_t q_stride = 0) {
+                       int axis, const float *q = nullptr, int64_t q_stride = 0, const int32_t *idx = nullptr) {
     return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
-                  tile_rec, grid, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), axis, 0};
+                  tile_rec, grid, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), (gi32p)idx, axis, 0};
 }
 
 template <typename T>
@@ -2420,6 +2484,7 @@ struct yawhip_ctx {
                              // 1, 2, 4 and 8 measure the same at the headline)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
+    int triple_runs = 1;     // float32 band kernels stream merged triple runs (k_merge_triples) when the partner strips are c - 1, c, c + 1
     int band_fp32 = 1;       // band kernel on strip layouts of unit vectors: float32 classification + exact float64 for the
                              // guard bands (k_count_band32); 0: every entry in float64 (k_count_band)
     double strip_width = 0.005;  // strip grid of newly uploaded catalogues (chord units, ~17 arcmin); 0 = no strips
@@ -2470,6 +2535,14 @@ struct StripLayout {
     int64_t *d_vbase = nullptr, *d_slo = nullptr, *d_tiles[3] = {nullptr, nullptr, nullptr};
     TileRec *d_tile_rec[3] = {nullptr, nullptr, nullptr};  // [tiles] first object, length and run of every lane tile
     RunGrid *d_grid = nullptr;        // [V+1] per-run index along the sort axis (item builder)
+    // merged triple runs (k_merge_triples), built when a float32 band kernel first streams this layout
+    bool triples = false;
+    float *q3 = nullptr;              // [3][q3_stride] float32 images in merged order (3 n entries)
+    int64_t q3_stride = 0;
+    double *w3 = nullptr;             // weights in merged order
+    int32_t *idx3 = nullptr;          // [3 n] entry -> index in the layout's own order
+    int64_t *off3 = nullptr;          // [V + 2 G + 1] offsets of the triple runs: group g has its strips + 2, first one = vbase[g] + 2 g
+    RunGrid *d_grid3 = nullptr;       // [V + 2 G + 1]
     int64_t n_groups = 0;
     int64_t device_bytes = 0;
     double obj_run = 0.0;             // run length seen by the typical object (sum len^2 / sum len)
@@ -2477,8 +2550,9 @@ struct StripLayout {
     void release() {
         for (void *ptr : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)q, (void *)off, (void *)d_vbase, (void *)d_slo,
                           (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_rec[0], (void *)d_tile_rec[1],
-                          (void *)d_tile_rec[2], (void *)d_grid})
+                          (void *)d_tile_rec[2], (void *)d_grid, (void *)q3, (void *)w3, (void *)idx3, (void *)off3, (void *)d_grid3})
             if (ptr) (void)hipFree(ptr);
+        q3 = nullptr; w3 = nullptr; idx3 = nullptr; off3 = nullptr; d_grid3 = nullptr; triples = false;
         x = y = z = w = nullptr; k = nullptr; q = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
         d_tile_rec[0] = d_tile_rec[1] = d_tile_rec[2] = nullptr;
@@ -2841,8 +2915,8 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     hipLaunchKernelGGL(k_run_offsets, dim3((unsigned)((n_runs + 1 + 255) / 256)), dim3(256), 0, ctx->stream, run_sorted, n, n_runs,
                        L.off);
     if (n_runs > 0)
-        hipLaunchKernelGGL(k_run_grid, dim3((unsigned)((n_runs * (RUN_GRID + 1) + 255) / 256)), dim3(256), 0, ctx->stream, n_runs, L.off,
-                           o == 0 ? L.x : (o == 1 ? L.y : L.z), L.d_grid);
+        hipLaunchKernelGGL(k_run_grid<double>, dim3((unsigned)((n_runs * (RUN_GRID + 1) + 255) / 256)), dim3(256), 0, ctx->stream, n_runs,
+                           L.off, o == 0 ? L.x : (o == 1 ? L.y : L.z), L.d_grid);
     std::vector<int64_t> voff((size_t)n_runs + 1);
     e = hipMemcpyAsync(voff.data(), L.off, (size_t)(n_runs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
     unsigned long long h_same = 0;
@@ -2904,6 +2978,65 @@ int build_strip_layout(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     c->device_bytes += L.device_bytes;
     L.built = true;
     return bail(hipSuccess, "");
+}
+
+// Merged triple runs of a built strip layout (see k_merge_triples); built once, on first use as the streamed side of a
+// float32 band kernel with partner strips c - 1, c, c + 1.
+int build_triples(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
+    StripLayout &L = seg ? c->seg[o] : c->strips[o];
+    if (!L.built) return fail(YAWHIP_ERR_INVALID, "build_triples: layout not built");
+    if (L.triples) return YAWHIP_OK;
+    const int64_t n = c->n, G = L.n_groups, V = L.h_vbase[(size_t)G], V3 = V + 2 * G;
+    if (3 * n >= (1ll << 31)) return fail(YAWHIP_ERR_INVALID, "build_triples: catalogue too large for 32-bit entry indices");
+    std::vector<int64_t> off3((size_t)V3 + 1, 0);
+    std::vector<int32_t> run_group((size_t)std::max<int64_t>(V, 1), 0);
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t lo = L.h_vbase[(size_t)g], hi = L.h_vbase[(size_t)g + 1];
+        for (int64_t r = lo; r < hi; ++r) run_group[(size_t)r] = (int32_t)g;
+        for (int64_t c_rel = 0; c_rel < hi - lo + 2; ++c_rel) {
+            const int64_t t = lo + 2 * g + c_rel, rc = lo + c_rel - 1;
+            int64_t len = 0;
+            for (int64_t m = rc - 1; m <= rc + 1; ++m)
+                if (m >= lo && m < hi) len += L.h_off[(size_t)m + 1] - L.h_off[(size_t)m];
+            off3[(size_t)t + 1] = len;
+        }
+    }
+    for (int64_t t = 0; t < V3; ++t) off3[(size_t)t + 1] += off3[(size_t)t];
+    if (off3[(size_t)V3] != 3 * n) return fail(YAWHIP_ERR_HIP, "build_triples: %lld entries for %lld objects", (long long)off3[(size_t)V3], (long long)n);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t n3 = (size_t)std::max<int64_t>(3 * n, 1);
+    L.q3_stride = (int64_t)((n3 + 3) & ~(size_t)3) + 8;  // as q_stride: a 16-byte load may run up to 12 bytes past a column
+    int32_t *d_run_group = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&L.q3), (size_t)3 * L.q3_stride * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.idx3), n3 * sizeof(int32_t));
+    if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w3), n3 * sizeof(double) + 16);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off3), (size_t)(V3 + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_grid3), (size_t)(V3 + 1) * sizeof(RunGrid));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_run_group), run_group.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(L.q3, 0, (size_t)3 * L.q3_stride * sizeof(float), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(L.d_grid3, 0, (size_t)(V3 + 1) * sizeof(RunGrid), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(L.off3, off3.data(), (size_t)(V3 + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_run_group, run_group.data(), run_group.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n > 0) {
+        hipLaunchKernelGGL(k_merge_triples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, V, L.off, d_run_group,
+                           L.d_vbase, L.off3, o == 0 ? L.x : (o == 1 ? L.y : L.z), L.q, L.q_stride, L.w, L.q3, L.q3_stride, L.w3, L.idx3);
+        hipLaunchKernelGGL(k_run_grid<float>, dim3((unsigned)((V3 * (RUN_GRID + 1) + 255) / 256)), dim3(256), 0, ctx->stream, V3, L.off3,
+                           L.q3 + (size_t)o * L.q3_stride, L.d_grid3);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (d_run_group) (void)hipFree(d_run_group);
+    if (e != hipSuccess) {
+        for (void *ptr : {(void *)L.q3, (void *)L.w3, (void *)L.idx3, (void *)L.off3, (void *)L.d_grid3})
+            if (ptr) (void)hipFree(ptr);
+        L.q3 = nullptr; L.w3 = nullptr; L.idx3 = nullptr; L.off3 = nullptr; L.d_grid3 = nullptr;
+        return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "merged triple runs failed: %s", hipGetErrorString(e));
+    }
+    const int64_t bytes = 3 * L.q3_stride * (int64_t)sizeof(float) + (int64_t)n3 * (4 + (c->w ? 8 : 0)) + (V3 + 1) * (int64_t)(sizeof(int64_t) + sizeof(RunGrid));
+    L.device_bytes += bytes;
+    c->device_bytes += bytes;
+    L.triples = true;
+    return YAWHIP_OK;
 }
 
 }  // namespace
@@ -3004,6 +3137,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
     if (!strcmp(key, "hist_copies_log2")) {
         if (value < -1 || value > 6) return fail(YAWHIP_ERR_INVALID, "hist_copies_log2 must be -1 (auto) or 0..6");
         ctx->hist_copies_log2 = (int)value;
+        return YAWHIP_OK;
+    }
+    if (!strcmp(key, "triple_runs")) {
+        ctx->triple_runs = value != 0;
         return YAWHIP_OK;
     }
     if (!strcmp(key, "spin_wait")) {
@@ -3234,7 +3371,7 @@ struct CallState {
     size_t o_ctr = 0, o_counts = 0, o_sums = 0;
     bool want_counts = false, want_sums = false, band_ran = false, run_unweighted = false, run_weighted = false;
     int64_t cand = 0, abytes = 0, n_pot = 0;
-    int launches = 0, kernel = 0, mode = 0, n_orient = 0, band_variant = 0;
+    int launches = 0, kernel = 0, mode = 0, n_orient = 0, band_variant = 0, merged_triples = 0;
 };
 
 // Float32 bounds of every edge for k_count_band32 (see there): for unit vectors rounded to float32,
@@ -3475,6 +3612,19 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         swap = false;
         c_lane = c2; c_strm = c1; LL = L2; LS = L1;
     }
+    // Merged triple runs on the streamed side: one window per item instead of three (k_merge_triples), when the partner
+    // strips are exactly c - 1, c, c + 1 (grid at least as wide as the largest separation).
+    bool triple = false;
+    if ((band32 || band_fine) && strip_items && ctx->triple_runs && c_strm->n < (1ll << 31) && c1->strip_width > 0.0 &&
+        (int)std::floor(rwin_max / c1->strip_width + 1e-6) + 1 == 1) {
+        triple = true;
+        for (int o = 0; o < 3 && triple; ++o) {
+            if (!LS[o]) continue;
+            const int rc = build_triples(ctx, const_cast<yawhip_catalog *>(c_strm), o, mode == 3);
+            if (rc == YAWHIP_ERR_OOM) triple = false;  // no room for the copies: three windows per item as before
+            else if (rc != YAWHIP_OK) return rc;
+        }
+    }
     int R = ctx->tile_r;
     double est_window = 0.0;  // band kernel: expected entries of one window
     if (R == 0) {
@@ -3515,7 +3665,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 return ((double)c->n / (double)runs) / std::max(extent, 1e-6);
             };
             const double d1 = per_u(c_strm, LS), d2 = per_u(c_lane, LL);
-            est_window = 64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1;
+            est_window = (64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1) * (triple ? 3.0 : 1.0);
         }
     }
     if (band && R == 0) R = 2;
@@ -3612,6 +3762,11 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 jr.k_off = lo2 - sl2.h_vbase[(size_t)q] - lo1;  // strip index of lane run r2 on the common grid, relative to group p
                 jr.vbase1 = sl1.h_vbase[(size_t)p];
                 jr.n_strips1 = (int32_t)cnt1;
+                if (triple) {  // triple runs of group p: strips [lo1 - 1, lo1 + cnt1], the first one at vbase + 2 p
+                    jr.k_off += 1;
+                    jr.vbase1 += 2 * (int64_t)p;
+                    jr.n_strips1 += 2;
+                }
                 n_items += (tiles[(size_t)(r0 + s_hi - s_lo + 1)] - tiles[(size_t)r0]) * ((2 * reach + 1 + MAX_WIN - 1) / MAX_WIN);
             }
         }
@@ -3678,6 +3833,14 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                                  a.d_tile_rec[tile_idx], a.d_grid, o, a.q, a.q_stride);
             h_tabs[3 + o] = make_tab(b.x, b.y, b.z, b.w, nullptr, b.off, b.d_vbase, b.d_slo, b.d_tiles[tile_idx],
                                      b.d_tile_rec[tile_idx], b.d_grid, o, b.q, b.q_stride);
+            if (triple) {
+                // the streamed side as merged triple runs: images, weights, offsets and grid index of the triples; the float64
+                // columns stay the layout's own (reached through idx by the exact re-evaluation)
+                const StripLayout &st = swap ? b : a;
+                DevTab &tb = h_tabs[swap ? 3 + o : o];
+                tb = make_tab(st.x, st.y, st.z, st.w3, nullptr, st.off3, st.d_vbase, st.d_slo, st.d_tiles[tile_idx],
+                              st.d_tile_rec[tile_idx], st.d_grid3, o, st.q3, st.q3_stride, st.idx3);
+            }
         }
     } else {
         h_tabs[0] = make_tab(c1->x, c1->y, c1->z, c1->w, nullptr, c1->off, nullptr, nullptr, nullptr, nullptr, nullptr, c1->axis);
@@ -3750,8 +3913,9 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         const unsigned bgrid = (unsigned)((n_pot + bwg - 1) / bwg);
         if (strip_items)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(bwg), 0, ctx->stream, ctx->d_tabs.ptr,
-                               reinterpret_cast<const JobRec *>(ctx->d_jobs.ptr), ctx->d_prefix.ptr, (int)n_sjobs, reach,
-                               (int)tile, rwin_max, swap ? 1 : 0, n_pot, ctx->d_items.ptr, ctx->d_ctr.ptr, kept_flags);
+                               reinterpret_cast<const JobRec *>(ctx->d_jobs.ptr), ctx->d_prefix.ptr, (int)n_sjobs,
+                               triple ? 0 : reach, (int)tile, rwin_max, swap ? 1 : 0, triple ? 1 : 0, n_pot, ctx->d_items.ptr,
+                               ctx->d_ctr.ptr, kept_flags);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
@@ -4044,6 +4208,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     cs.launches = launches; cs.kernel = kernel; cs.mode = mode;
     cs.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
     cs.band_variant = !band_ran ? 0 : (band32 ? 32 : (band_fine ? 33 : 64));
+    cs.merged_triples = band_ran && triple ? 1 : 0;
     g_trace.mark("launched");
     return YAWHIP_OK;
 }
@@ -4117,6 +4282,7 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         stats->layout_mode = cs.mode;
         stats->n_orientations = cs.n_orient;
         stats->band_variant = cs.band_variant;
+        stats->merged_triples = cs.merged_triples;
         if (cs.band_ran)
             for (int i = 0; i < EVAL_SLOTS; ++i) stats->exact_reevaluations += (int64_t)ctr[9 + 8 * (size_t)i];
         stats->kernel_ms = ms;
@@ -4135,6 +4301,7 @@ void add_stats(yawhip_stats &total, const yawhip_stats &part, bool side_by_side)
     total.layout_mode = part.layout_mode;
     total.n_orientations = std::max(total.n_orientations, part.n_orientations);
     total.band_variant = part.band_variant;
+    total.merged_triples = part.merged_triples;
     total.exact_reevaluations += part.exact_reevaluations;
     if (side_by_side) {  // devices of one call run at the same time: the slowest counts
         total.kernel_ms = std::max(total.kernel_ms, part.kernel_ms);
