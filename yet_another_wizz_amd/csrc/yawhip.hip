@@ -1763,6 +1763,9 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                 ax2[h] = f32x2{ax[2 * h], ax[2 * h + 1]}; ay2[h] = f32x2{ay[2 * h], ay[2 * h + 1]}; az2[h] = f32x2{az[2 * h], az[2 * h + 1]};
             }
         }
+        f32x2 nc2[R / 2 > 0 ? R / 2 : 1];  // one annulus: -c of the lane's objects, the addend of the first product
+#pragma unroll
+        for (int h = 0; h < R / 2; ++h) nc2[h] = f32x2{-th[2 * h][0], -th[2 * h + 1][0]};
         unsigned int cnt[R][NC];
         double acc[R][NC];
 #pragma unroll
@@ -1889,17 +1892,23 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                 cnt[0][0] += __float_as_uint(en.x) ^ __float_as_uint(en.y) ^ __float_as_uint(en.z);  // diagnostics: the LDS reads alone
                 return;
 #endif
+                // One annulus: the centre c of the annulus is the addend of the first product, q = s32 - c comes out of the three
+                // fused multiply-adds (no subtraction per evaluation; the host widens both classes by the rounding of the
+                // intermediate sums, build_thr32). More edges: s32 itself.
                 float s32[R];
                 if constexpr (R >= 2) {
 #pragma unroll
                     for (int h = 0; h < R / 2; ++h) {
                         const f32x2 dx = ax2[h] - en.x, dy = ay2[h] - en.y, dz = az2[h] - en.z;
-                        const f32x2 sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+                        f32x2 sq;
+                        if constexpr (NE == 2) sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, nc2[h])));
+                        else sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
                         s32[2 * h] = sq.x; s32[2 * h + 1] = sq.y;
                     }
                 } else {
                     const float dx = ax[0] - en.x, dy = ay[0] - en.y, dz = az[0] - en.z;
-                    s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    if constexpr (NE == 2) s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, -th[0][0])));
+                    else s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                 }
                 // classes as wave masks: "certainly inside / below" feeds the lane counters (add with carry), "possibly" stays
                 // on the scalar unit -- undecided = possibly & ~certainly costs no vector instruction
@@ -1908,7 +1917,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if constexpr (NE == 2) {
-                        const float q = __builtin_fabsf(s32[r] - th[r][0]);
+                        const float q = __builtin_fabsf(s32[r]);  // |s32 - c|
                         const bool in = q < th[r][1];
                         unc_mask[r] = __builtin_amdgcn_ballot_w64(q < th[r][2]) & ~__builtin_amdgcn_ballot_w64(in);
                         // weighted: acc += w of the entry where inside -- as an fma with the multiplier 1.0 / 0.0 (exact: the same
@@ -3139,8 +3148,9 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->hist_copies_log2 = (int)value;
         return YAWHIP_OK;
     }
-    if (!strcmp(key, "triple_runs")) {
-        ctx->triple_runs = value != 0;
+    if (!strcmp(key, "triple_runs")) {  // 0: never, 1: where the merged window fits the stage, 2: wherever the partner strips are c - 1, c, c + 1
+        if (value < 0 || value > 2) return fail(YAWHIP_ERR_INVALID, "triple_runs must be 0, 1 or 2");
+        ctx->triple_runs = (int)value;
         return YAWHIP_OK;
     }
     if (!strcmp(key, "spin_wait")) {
@@ -3378,7 +3388,7 @@ struct CallState {
 //   |s32 - s| <= g(t) = 2.1e-7 sqrt(t) + 5e-7 t + 1e-12 near s = t,
 // so s32 < t - g proves s <= t and s32 > t + g proves s > t; in between the kernel evaluates in float64.
 //   n_edges == 2: {c, h_in, h_out, 0}: |s32 - c| < h_in proves t0 < s <= t1, |s32 - c| >= h_out proves the opposite
-//                 (both widths carry the rounding of the float32 subtraction);
+//                 (s32 - c is what the kernel's three fused multiply-adds deliver; both widths carry their rounding);
 //   else per edge {t - g rounded down, t + g rounded up}.
 std::vector<float> build_thr32(const double *t, int n_bins, int n_edges) {
     auto down = [](double v) { float f = (float)v; if ((double)f > v) f = nextafterf(f, -INFINITY); return f; };
@@ -3393,8 +3403,11 @@ std::vector<float> build_thr32(const double *t, int n_bins, int n_edges) {
             const double g0 = guard(tk[0]), g1 = guard(tk[1]);
             const float c = (float)(0.5 * (tk[0] + tk[1]));
             const double cd = (double)c;
-            const double h_in = std::min(cd - (tk[0] + g0), (tk[1] - g1) - cd) * (1.0 - 1e-6);
-            const double h_out = std::max(cd - (tk[0] - g0), (tk[1] + g1) - cd) * (1.0 + 1e-6);
+            // q = fma(dz, dz, fma(dy, dy, fma(dx, dx, -c))): three roundings of intermediate sums that stay below 2 c wherever
+            // a class is claimed (|q| < h_in <= c, or s inside the annulus: s32 <= t1 + g1 <= 2 c) -> 6 x 2^-24 x c = 3.6e-7 c
+            const double fold = 4e-7 * cd;
+            const double h_in = (std::min(cd - (tk[0] + g0), (tk[1] - g1) - cd) - fold) * (1.0 - 1e-6);
+            const double h_out = (std::max(cd - (tk[0] - g0), (tk[1] + g1) - cd) + fold) * (1.0 + 1e-6);
             row[0] = c;
             row[1] = h_in > 0.0 ? down(h_in) : 0.f;   // |q| < 0 never holds: nothing is certain
             row[2] = up(std::max(h_out, 0.0));
@@ -3612,19 +3625,6 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         swap = false;
         c_lane = c2; c_strm = c1; LL = L2; LS = L1;
     }
-    // Merged triple runs on the streamed side: one window per item instead of three (k_merge_triples), when the partner
-    // strips are exactly c - 1, c, c + 1 (grid at least as wide as the largest separation).
-    bool triple = false;
-    if ((band32 || band_fine) && strip_items && ctx->triple_runs && c_strm->n < (1ll << 31) && c1->strip_width > 0.0 &&
-        (int)std::floor(rwin_max / c1->strip_width + 1e-6) + 1 == 1) {
-        triple = true;
-        for (int o = 0; o < 3 && triple; ++o) {
-            if (!LS[o]) continue;
-            const int rc = build_triples(ctx, const_cast<yawhip_catalog *>(c_strm), o, mode == 3);
-            if (rc == YAWHIP_ERR_OOM) triple = false;  // no room for the copies: three windows per item as before
-            else if (rc != YAWHIP_OK) return rc;
-        }
-    }
     int R = ctx->tile_r;
     double est_window = 0.0;  // band kernel: expected entries of one window
     if (R == 0) {
@@ -3665,10 +3665,31 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 return ((double)c->n / (double)runs) / std::max(extent, 1e-6);
             };
             const double d1 = per_u(c_strm, LS), d2 = per_u(c_lane, LL);
-            est_window = (64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1) * (triple ? 3.0 : 1.0);
+            est_window = 64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1;
         }
     }
     if (band && R == 0) R = 2;
+    // Merged triple runs on the streamed side: one window per item instead of three (k_merge_triples), when the partner
+    // strips are exactly c - 1, c, c + 1 (grid at least as wide as the largest separation) AND the merged window still goes
+    // through the stage in one piece: cut in pieces it costs more than three whole windows (100M x 100M: 22.0 against 14.9 ms,
+    // 50M x 50M with three scales 25.8 against 17.9). Weighted runs and the fine-grid kernel have less room (a larger stage
+    // costs them residency: weighted headline 0.55 against 0.51 ms, 51 fine bins 1.40 against 1.15 in a 512-entry stage),
+    // so they merge only windows that fit the stage they use anyway (sparse streamed sides: DR of config #4 2.07 against 2.43).
+    bool triple = false;
+    if ((band32 || band_fine) && strip_items && ctx->triple_runs && c_strm->n < (1ll << 31) && c1->strip_width > 0.0 &&
+        (int)std::floor(rwin_max / c1->strip_width + 1e-6) + 1 == 1) {
+        const double est3 = 3.0 * est_window;
+        triple = ctx->triple_runs == 2 ||
+                 (band32 ? est3 <= (weighted_any ? 0.75 * (B32_CAP - 4) : 0.88 * (B32_CAP_BIG - 4)) : est3 <= 0.9 * BCAP_MID);
+        for (int o = 0; o < 3 && triple; ++o) {
+            if (!LS[o]) continue;
+            const int rc = build_triples(ctx, const_cast<yawhip_catalog *>(c_strm), o, mode == 3);
+            if (rc == YAWHIP_ERR_OOM) triple = false;  // no room for the copies: three windows per item as before
+            else if (rc != YAWHIP_OK) return rc;
+        }
+        if (triple) est_window = est3;
+    }
+    if (g_trace.on) fprintf(stderr, "[yawhip trace] est_window %.1f (triple %d) R %d mode %d\n", est_window, (int)triple, R, mode);
     // stage capacity of the band kernel: the smallest compiled one that holds a whole window (see BCAP_MID)
     int cap = ctx->band_cap == BCAP || ctx->band_cap == BCAP_MID ? ctx->band_cap : 0;
     if (band && cap == 0) cap = R >= 4 || est_window > 0.95 * BCAP ? BCAP_MID : BCAP;
