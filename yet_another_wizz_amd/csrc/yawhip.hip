@@ -172,6 +172,9 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_UNROLL
 #define YAW_B32_UNROLL 1  // entries per trip of the walk loop: 1, 2 and 4 measure the same (0.362 / 0.366 / 0.374 ms at the headline)
 #endif
+#ifndef YAW_B32_SHARE
+#define YAW_B32_SHARE 1  // bands of sparse single-window items are shared out over the wave (k_count_band32)
+#endif
 #ifndef YAW_B32_WAVES_W
 #define YAW_B32_WAVES_W 5  // waves per SIMD the weighted one-annulus variants are compiled for (96 VGPRs; the compiler took 97 by itself: 4 waves, 0.57 against 0.51 ms)
 #endif
@@ -1565,6 +1568,30 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 //   NE == 2 (one annulus): classes by |s32 - c| against two half widths (certainly inside / possibly inside);
 //   NE  > 2: cumulative counters per edge (s <= t_e), fine bin j = cum[j + 1] - cum[j] at the flush.
 // ------------------------------------------------------------------------------------------------
+// Items -> XCDs (float32 band kernels). Workgroup v runs on XCD v & 7 and takes the items of that XCD one after the other.
+// The list arrives in the order of the jobs -- diagonal jobs first (dense lane tiles), then the tiles at patch borders
+// (windows that reach a few lanes only) -- so eight contiguous eighths would give six XCDs the heavy items and two the light
+// ones. The list is cut into BLOCKS of 2^bs consecutive items (consecutive items are neighbouring lane tiles: their windows
+// overlap, which is what an XCD's L2 is for) and the blocks are dealt round robin to the XCDs.
+struct TicketMap {
+    unsigned long long per_xcd;  // tickets an XCD walks through (multiple of the block size)
+    unsigned bs;                 // log2 of the block size
+    __device__ __forceinline__ unsigned long long ticket(unsigned long long v) const {
+        const unsigned long long j = v >> 3;
+        return ((((j >> bs) << 3) + (v & 7)) << bs) + (j & ((1ull << bs) - 1ull));
+    }
+};
+__device__ __forceinline__ TicketMap ticket_map(unsigned long long n_kept) {
+    TicketMap m;
+    const unsigned long long want = n_kept >> 7;  // ~16 blocks per XCD
+    int bs = want > 1 ? 63 - __builtin_clzll(want) : 0;
+    bs = bs < 6 ? 6 : (bs > 12 ? 12 : bs);
+    m.bs = (unsigned)bs;
+    const unsigned long long nblocks = (n_kept + (1ull << bs) - 1ull) >> bs;
+    m.per_xcd = ((nblocks + 7ull) >> 3) << bs;
+    return m;
+}
+
 constexpr float PAD_COORD32 = 4.0f;
 constexpr double BAND32_GUARD_SQRT = 2.1e-7;  // coefficient of sqrt(t) in the float32 guard g(t), see k_count_band32
 // float32 words per bin of the threshold table: NE == 2: {c, h_in, h_out, 0}; else per edge {t - g, t + g}
@@ -1646,15 +1673,15 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
     const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
 
     const unsigned long long n_kept = counters[0];
-    const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    const TicketMap tmap = ticket_map(n_kept);
     for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
     if (LANE_THR)
         for (int e = lane; e < n_bins * TW; e += 64) sthr[e] = thr32[e];
     unsigned round_no = 0;
     for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
-        if ((v >> 3) >= chunk) break;
-        const unsigned long long ticket = (v & 7) * chunk + (v >> 3);
-        if (ticket >= n_kept) continue;  // short last eighth
+        if ((v >> 3) >= tmap.per_xcd) break;
+        const unsigned long long ticket = tmap.ticket(v);
+        if (ticket >= n_kept) continue;  // beyond the last block's end
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
         const DevTab cl = tabs[swap ? o : 3 + o], cs = tabs[swap ? 3 + o : o];  // lane side, streamed side
@@ -1727,6 +1754,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
         f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
         float ax[R], ay[R], az[R];
         int kb[R];
+        int lane_obj = lane;  // whose objects this lane counts for: its own, until the bands of a sparse item are shared out
         int n_own = (int)it.na - lane * R;
         n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
 #pragma unroll
@@ -1785,7 +1813,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                         // float64 adds of ONE instruction that hit the same cell are serialised by the LDS in a fixed lane
                         // order; the histogram belongs to this wave alone -> reproducible sums
                         // (the object's own weight is fetched here, once per item, instead of living in registers through the walk)
-                        const double aw = (cl.w && r < n_own) ? (cl.w + it.a0)[lane * R + r] : 1.0;
+                        const double aw = (cl.w && r < n_own) ? (cl.w + it.a0)[lane_obj * R + r] : 1.0;
                         if (vsum != 0.0)
                             (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw * vsum,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1810,6 +1838,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
             }
         };
 
+        const bool single_window = it.nwin == 1 && it.nb[0] + 1 <= CAP;  // the item is this one chunk (see YAW_B32_SHARE)
         for (;; ++round_no) {
             // The round has landed: nothing but the issuing wave's own vmcnt orders an LDS read behind a pending LDS-DMA. The
             // wait is spelled out -- in a single-wave workgroup __syncthreads() is no barrier instruction, and on this loop's
@@ -1840,7 +1869,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                 ql[c] = qh[c] = a_key[c] - 4u;
                 n_max = cn[c] > n_max ? cn[c] : n_max;
             }
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 2
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 2
             for (unsigned step = 0; step >= 4u; step >>= 1) {  // diagnostics: no search either
 #else
             for (unsigned step = 4u << (31 - __builtin_clz(n_max)); step >= 4u; step >>= 1) {  // largest power of two <= n_max
@@ -1862,12 +1891,72 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
             const int n = cn[c];
             int lo = (int)((ql[c] + 4u - a_key[c]) >> 2), hi = (int)((qh[c] + 4u - a_key[c]) >> 2);
             if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
-            const int len = hi - lo;
+            int len = hi - lo;
+            unsigned stride = 4u;  // bytes between the entries a lane evaluates (wave-uniform)
+#if !defined(YAW_BAND_DIAG) || YAW_BAND_DIAG != 3
             nev += (unsigned int)(len * n_own);
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1
+#endif
+#if YAW_B32_SHARE
+            // Sparse items -- a lane tile at the border of its patch whose partner run reaches only a few of its objects, the
+            // short last tile of a run: the walk takes as many trips as the longest band however few lanes have one (a seventh
+            // of all trips at the headline belonged to windows with bands in at most 32 lanes). When the lanes with a band
+            // span at most half the wave, their bands are SHARED OUT: 2, 4 or 8 lanes take the objects of one lane (register
+            // shuffles) and every 2nd, 4th or 8th entry of its band each. Counters and bins travel with the objects, so this is done only where the
+            // item consists of this one window (the lane counters are still zero and are flushed with the new owners).
+            if (single_window) {
+                const unsigned long long act = __builtin_amdgcn_ballot_w64(len > 0);
+                const int first = act ? __builtin_ctzll(act) : 0, span = act ? 64 - __builtin_clzll(act) - first : 64;
+                if (span <= 32) {
+                    const int sh = span <= 8 ? 3 : (span <= 16 ? 2 : 1);
+                    const bool idle = (lane >> sh) >= span;  // groups beyond the lanes that have a band: nothing to take
+                    const int src = idle ? first : first + (lane >> sh);
+                    const int part = lane & ((1 << sh) - 1);
+                    if constexpr (R >= 2) {
+#pragma unroll
+                        for (int h = 0; h < R / 2; ++h) {
+                            ax2[h] = f32x2{__shfl(ax2[h].x, src, 64), __shfl(ax2[h].y, src, 64)};
+                            ay2[h] = f32x2{__shfl(ay2[h].x, src, 64), __shfl(ay2[h].y, src, 64)};
+                            az2[h] = f32x2{__shfl(az2[h].x, src, 64), __shfl(az2[h].y, src, 64)};
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if constexpr (R < 2) { ax[r] = __shfl(ax[r], src, 64); ay[r] = __shfl(ay[r], src, 64); az[r] = __shfl(az[r], src, 64); }
+                        if constexpr (MERGED) kb[r] = __shfl(kb[r], src, 64);
+                        if constexpr (LANE_THR) {
+#pragma unroll
+                            for (int q = 0; q < TW; ++q) th[r][q] = sthr[kb[r] * TW + q];
+                        }
+                    }
+                    if constexpr (LANE_THR && NE == 2) {
+#pragma unroll
+                        for (int h = 0; h < R / 2; ++h) nc2[h] = f32x2{-th[2 * h][0], -th[2 * h + 1][0]};
+                    }
+                    n_own = __shfl(n_own, src, 64);
+                    lane_obj = src;
+                    // lane `part` of a group takes the entries lo + part, lo + part + S, ... of the band: a lane that walks on
+                    // past its share (the trip count is the wave's) meets the entries of no other lane of its group, and beyond
+                    // the band entries that fail the predicate by themselves -- as on the ordinary walk
+                    const int lo_s = __shfl(lo, src, 64), len_s = __shfl(len, src, 64);
+                    lo = idle ? n : lo_s + part;  // (idle lanes walk the sentinel)
+                    len = !idle && len_s > part ? (len_s - part + (1 << sh) - 1) >> sh : 0;
+                    stride = 4u << sh;
+                }
+            }
+#endif
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1 && YAW_BAND_DIAG != 3
             const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
 #else
             const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
+#endif
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 3
+#ifdef YAW_DIAG_ACT   // ... of the (item, window)s with at most YAW_DIAG_ACT lanes that have a band at all
+            int act = __popcll(__builtin_amdgcn_ballot_w64(len > 0));
+            asm volatile("" : "+s"(act));  // the ballot stays in front of the lane-0 branch
+            nev += lane == 0 && act <= YAW_DIAG_ACT ? (unsigned int)steps : 0u;
+#else
+            nev += lane == 0 ? (unsigned int)steps : 0u;  // diagnostics: "evaluated" reports the trips of the walk
+#endif
 #endif
 
             const unsigned a_chunk = a_stage + ((unsigned)co[c] << 2);
@@ -1942,7 +2031,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane * R + r, cs.x, cs.y, cs.z,
+                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane_obj * R + r, cs.x, cs.y, cs.z,
                                                                       cs.idx ? (int64_t)cs.idx[cb[c] + eidx] : cb[c] + (int64_t)eidx,
                                                                       t + (size_t)(MERGED ? kb[r] : kfix) * NE,
                                                                       counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
@@ -1967,10 +2056,10 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
             for (int s = 0; s < steps; s += YAW_B32_UNROLL) {
 #pragma unroll
                 for (int uu = 0; uu < YAW_B32_UNROLL; ++uu) {
-                    const unsigned at = cur + 4u * (unsigned)uu;
+                    const unsigned at = cur + stride * (unsigned)uu;
                     eval_entry(at < last ? at : last);
                 }
-                cur += 4u * YAW_B32_UNROLL;
+                cur += stride * YAW_B32_UNROLL;
             }
             }
             }
@@ -2050,13 +2139,13 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
     const unsigned a_dummy = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(dummy + lane);
 
     const unsigned long long n_kept = counters[0];
-    const unsigned long long chunk = (n_kept + 7) >> 3;  // items per XCD
+    const TicketMap tmap = ticket_map(n_kept);
     for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
     for (int e = lane; e < rows * tw; e += 64) stab[e] = fine32[e];
     unsigned stage_no = 0;
     for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
-        if ((v >> 3) >= chunk) break;
-        const unsigned long long ticket = (v & 7) * chunk + (v >> 3);
+        if ((v >> 3) >= tmap.per_xcd) break;
+        const unsigned long long ticket = tmap.ticket(v);
         if (ticket >= n_kept) continue;
         const Item it = items[ticket];
         const int o = item_orient(it), islot = item_slot(it);
