@@ -219,7 +219,13 @@ struct JobRec {    // per job of a call
 // table is built and when it is queried, so for any w the first entry with key >= w and the first with key > w both lie in
 // [g[cell(w)], g[cell(w) + 1]] -- exactly, whatever the rounding of the product: the bisection over a run of 900 entries
 // (ten dependent loads) becomes one table look-up and four steps.
-constexpr int RUN_GRID = 64;
+#ifndef YAW_RUN_GRID
+#define YAW_RUN_GRID 64
+#endif
+#ifndef YAW_BUILD_BISECT
+#define YAW_BUILD_BISECT 32  // bisection steps of the strip builder inside a grid cell (fewer: the window is a superset, a few entries longer)
+#endif
+constexpr int RUN_GRID = YAW_RUN_GRID;
 struct RunGrid {
     double inv;                  // RUN_GRID / (last - first), 0 for a run with one distinct key
     uint32_t g[RUN_GRID + 2];    // + 1 pad: 8-byte multiple
@@ -508,7 +514,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
             sl[j] = l0; sh[j] = l1; ul[j] = u0; uh[j] = u1;  // all 0 for a dead window
         }
         // lower bounds (first index with key >= wlo) and upper bounds (first index with key > whi), all at once
-        while ((sl[0] < sh[0]) | (sl[1] < sh[1]) | (sl[2] < sh[2]) | (ul[0] < uh[0]) | (ul[1] < uh[1]) | (ul[2] < uh[2])) {
+        for (int step = 0; step < YAW_BUILD_BISECT &&
+                           ((sl[0] < sh[0]) | (sl[1] < sh[1]) | (sl[2] < sh[2]) | (ul[0] < uh[0]) | (ul[1] < uh[1]) | (ul[2] < uh[2])); ++step) {
             double kl[MAX_WIN], ku[MAX_WIN];
             uint32_t ml[MAX_WIN], mu[MAX_WIN];
 #pragma unroll
@@ -526,9 +533,9 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
             }
         }
 #pragma unroll
-        for (int j = 0; j < MAX_WIN; ++j) {
+        for (int j = 0; j < MAX_WIN; ++j) {  // (a search cut short leaves sl <= first entry of the window, uh >= its end)
             wb[j] += sl[j];
-            wn[j] = (int32_t)(ul[j] - sl[j]);  // 0 for a dead window
+            wn[j] = (int32_t)((YAW_BUILD_BISECT < 32 ? uh[j] : ul[j]) - sl[j]);  // 0 for a dead window
         }
 #pragma unroll
         for (int j = 0; j < MAX_WIN; ++j) {  // non-empty windows to the front
@@ -1944,7 +1951,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                 }
             }
 #endif
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1 && YAW_BAND_DIAG != 3
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1 && YAW_BAND_DIAG < 3
             const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
 #else
             const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
@@ -1960,7 +1967,11 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
 #endif
 
             const unsigned a_chunk = a_stage + ((unsigned)co[c] << 2);
+#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 4
+            unsigned cur = a_chunk + ((unsigned)lane << 2);  // diagnostics: the walk without LDS bank conflicts (wrong counts)
+#else
             unsigned cur = a_chunk + ((unsigned)lo << 2);
+#endif
             const unsigned last = a_chunk + ((unsigned)n << 2);
             // One entry per evaluation step: three 4-byte reads from columns a fixed distance apart (lanes read nearly
             // consecutive words of a column). YAW_B32_UNROLL entries per trip of the loop: their LDS reads go out together and the
