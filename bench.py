@@ -438,7 +438,11 @@ def main():
                                                  "are never evaluated"),
             )
         roofline.update(
-            kernel={1: "k_count (exact path)", 4: "k_count_band (band path)"}.get(stats.kernel_used, f"k_count_merged ({kernel_name} path)"),
+            kernel={1: "k_count (exact path)",
+                    4: {32: "k_count_band32 (band path, float32 classes + exact float64 guard bands)",
+                        33: "k_count_band32_fine (band path, fine radial grid)"}.get(getattr(stats, "band_variant", 0),
+                                                                                    "k_count_band (band path, float64)"),
+                    }.get(stats.kernel_used, f"k_count_merged ({kernel_name} path)"),
             launch_ms=count_ms, all_kernels_ms=stats.kernel_ms,
             fixed_cost_ms=elapsed / max(args.steps, 1) * 1e3 - count_ms,  # everything of a step that is not the count kernel
             culled_fraction=1.0 - stats.evaluated_pairs / max(stats.candidate_pairs, 1),
@@ -457,6 +461,8 @@ def main():
             metric="candidate pairs/s", value=value, unit="pairs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=elapsed / max(args.steps, 1) * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None,
             dtype="f64", data="synthetic",
+            dtype_note="every pair is decided as the float64 predicate decides it (results identical to the all-float64 kernels); "
+                       "the default band kernel classifies in float32 and re-evaluates the pairs inside its guard bands in float64",
             config=dict(
                 workload=f"{int(args.n_ref)} ref x {int(args.n_unk)} unk uniform full sky, {args.zbins} z-bins, "
                          f"{args.patches} patches, "

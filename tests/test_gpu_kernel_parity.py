@@ -139,6 +139,54 @@ def test_ragged_jobs_vs_oracle(ctx, kernel, nb2, weights):
     ctx.set_option("tile_r", 0)
 
 
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+@pytest.mark.parametrize("n1", [300, 1200, 2600])
+def test_sparse_items_share_their_bands(ctx, n1, weights):
+    """Lane tiles with a handful of objects facing ONE window that fits the stage: k_count_band32 shares the bands of the few
+    lanes that have one out over the wave (8, 4 or 2 lanes per lane's objects, every 8th / 4th / 2nd entry each; yawhip.hip,
+    YAW_B32_SHARE). Runs of ~15, ~60 and ~130 objects per (patch, strip); one annulus with common and with per-bin edges
+    (thresholds per lane object), two scales sharing no edge (four edges, cumulative counters), 1, 2 and 4 objects per lane,
+    with and without the strip grid, binned x unbinned and the binned catalogue against itself."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(4242 + n1)
+    P, B = 3, 4
+    c1 = _random_catalog(rng, n1, P, B, weights[0] == "w")
+    c2 = _random_catalog(rng, 5000, P, 1, weights[1] == "w")
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    arcmin = np.pi / 10800
+    one = oracle.parse_ang_limits([0.8 * arcmin], [4.0 * arcmin])
+    two = oracle.parse_ang_limits(np.array([0.5, 2.5]) * arcmin, np.array([2.0, 5.0]) * arcmin)
+    tables = {
+        "one annulus": np.tile(oracle.thresholds_for(oracle.ang_bins_for(one, None, None)), (B, 1)),
+        "per-bin annulus": np.stack([oracle.thresholds_for(oracle.ang_bins_for(one * (1.0 + 0.07 * k), None, None)) for k in range(B)]),
+        "four edges": np.tile(oracle.thresholds_for(oracle.ang_bins_for(two, None, None)), (B, 1)),
+    }
+    try:
+        for strip_micro in (_lib.DEFAULT_STRIP_MICRO, 0):
+            ctx.set_option("strip_width_micro", strip_micro)
+            d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+            for name, t in tables.items():
+                exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+                exp_self, exp_self_s = oracle.count_jobs(c1, c1, jobs, t)
+                assert exp_c.sum() > 200
+                for tile_r in (0, 1, 4):
+                    ctx.set_option("tile_r", tile_r)
+                    for (da, db, ec, es) in ((d1, d2, exp_c, exp_s), (d1, d1, exp_self, exp_self_s)):
+                        counts, sums, stats = _lib.count_pairs(ctx, da, db, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                        assert stats.kernel_used == _lib.KERNEL_BAND, (name, strip_micro)
+                        if strip_micro and db is d2:  # (sparse binned x binned counts run on the plain layout: float64 band kernel)
+                            assert stats.band_variant == 32, (name, stats.band_variant)
+                        assert np.array_equal(counts, ec), (name, strip_micro, tile_r)
+                        if weights == "uu":
+                            assert np.array_equal(sums, ec.astype(np.float64))
+                        else:
+                            np.testing.assert_allclose(sums, es, rtol=RTOL_W, atol=0)
+    finally:
+        ctx.set_option("tile_r", 0)
+        ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_empty_and_degenerate(ctx, kernel):
     from yet_another_wizz_amd import _lib
