@@ -178,6 +178,12 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_WAVES_W
 #define YAW_B32_WAVES_W 5  // waves per SIMD the weighted one-annulus variants are compiled for (96 VGPRs; the compiler took 97 by itself: 4 waves, 0.57 against 0.51 ms)
 #endif
+#ifndef YAW_B32_WAVES_BIG
+#define YAW_B32_WAVES_BIG 6  // ... the plain count with the big stage: its 6.3 KB of LDS admit 25 workgroups per CU anyway, and at 80 registers
+#endif                       // nothing is spilled (headline 0.305 -> 0.286 ms; 8: 0.343)
+#ifndef YAW_B32_WAVES_LT
+#define YAW_B32_WAVES_LT 1   // ... the plain count with per-bin thresholds (physical scales): the compiler's choice (87 registers, 5 waves)
+#endif
 #ifndef YAW_B32_WAVES
 #define YAW_B32_WAVES 1  // > 1: waves per SIMD every variant is compiled for (experiments). Default: 7 for the plain count (72 VGPRs
 #endif                   // instead of 79: 0.359 against 0.371 ms at the headline; 8 spills: 0.405), the compiler's choice elsewhere
@@ -1651,7 +1657,7 @@ constexpr int B32_CAP_BIG = YAW_B32_CAP_BIG;
 constexpr int B32_MAX_CHUNKS = 3;  // windows (or pieces of one) staged together in one round of k_count_band32
 
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 && UNI ? (WEIGHTED ? YAW_B32_WAVES_W : 7) : 1))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
+__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 && UNI ? (WEIGHTED ? YAW_B32_WAVES_W : (CAP >= YAW_B32_CAP_BIG ? YAW_B32_WAVES_BIG : 7)) : (NE == 2 && !WEIGHTED ? YAW_B32_WAVES_LT : 1)))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
                                                      const double *__restrict__ t, const float *__restrict__ thr32,
                                                      const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
                                                      unsigned long long *__restrict__ out_counts,
