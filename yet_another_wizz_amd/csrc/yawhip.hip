@@ -342,8 +342,16 @@ constexpr int BUILD_PREFIX_LDS = 1024;  // job tables up to this many entries ar
 // Append the kept items of a builder workgroup to the item list and add its evaluated-pair total: ONE atomic
 // per workgroup on each of the two counters. (They are single hot addresses -- with an atomic per wave the
 // builders spent three quarters of their time queueing on them.) Order of the list is irrelevant.
+// seg_cap > 0: the list is kept in ITEM_SEGS segments of seg_cap records, workgroup b appends to segment b % ITEM_SEGS and
+// counts in that segment's own counter (ITEM_SEG_CTR): eight addresses take the atomics of a launch side by side (on one
+// address the 1200 appends of the headline queue for 10 of the builder's 43 us), and a segment -- every eighth builder
+// workgroup's tiles -- is the same mix of dense and sparse items as the whole list: the float32 band kernels give XCD x
+// segment x.
+constexpr int ITEM_SEGS = 8;
+__host__ __device__ constexpr int ITEM_SEG_CTR(int seg) { return 12 + 8 * seg; }  // counters[]: one 64-byte line each
 __device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned long long work, Item *__restrict__ items,
-                                             unsigned long long *__restrict__ counters, unsigned char *__restrict__ kept) {
+                                             unsigned long long *__restrict__ counters, unsigned char *__restrict__ kept,
+                                             unsigned long long seg_cap = 0) {
     if (keep && kept) kept[it.pot] = 1;  // weighted runs: this potential item will write its slab
     __shared__ unsigned int s_cnt[BUILD_WG / 64];
     __shared__ unsigned long long s_work[BUILD_WG / 64], s_base;
@@ -364,7 +372,12 @@ __device__ __forceinline__ void append_items(bool keep, const Item &it, unsigned
             total += c;
             wsum += s_work[wv];
         }
-        s_base = total ? atomicAdd(&counters[0], (unsigned long long)total) : 0ull;
+        if (seg_cap) {
+            const int seg = (int)(blockIdx.x % ITEM_SEGS);
+            s_base = (unsigned long long)seg * seg_cap + (total ? atomicAdd(&counters[ITEM_SEG_CTR(seg)], (unsigned long long)total) : 0ull);
+        } else {
+            s_base = total ? atomicAdd(&counters[0], (unsigned long long)total) : 0ull;
+        }
         if (wsum) atomicAdd(&counters[10 + 8 * (blockIdx.x & (EVAL_SLOTS - 1))], wsum);  // statistics, spread like the other totals
     }
     __syncthreads();
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
                                                             const int64_t *__restrict__ prefix, int n_jobs, int reach,
                                                             int tile, double rwin, int swap, int triple, int64_t n_pot,
                                                             Item *__restrict__ items, unsigned long long *__restrict__ counters,
-                                                            unsigned char *__restrict__ kept) {
+                                                            unsigned char *__restrict__ kept, unsigned long long seg_cap) {
     // triple: the streamed side consists of merged triple runs (k_merge_triples) -- the host passes reach = 0 (one partner
     // run per lane tile: the triple centred on its strip) and the triples' offsets and grid index in the streamed table; their
     // sort key exists as float32 image only, so the window is widened by the rounding of a key (the count kernel searches
@@ -446,11 +459,16 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
     // Every thread walks a chain of dependent loads (job -> tile -> runs -> windows); its length is the kernel's run time.
     // The job table is small: searched in LDS (one coalesced load instead of log2(jobs) round trips to L2).
     __shared__ int64_t s_prefix[BUILD_PREFIX_LDS];
+    // ... and so are the six layout records: which one a thread needs depends on its job's orientation, so every pointer in
+    // them would be a vector load of its own in front of the load it points to (five round trips of the chain)
+    __shared__ DevTab s_tabs[6];
+    static_assert(sizeof(DevTab) % 8 == 0, "DevTab is copied in 8-byte words");
+    for (int e = threadIdx.x; e < (int)(6 * sizeof(DevTab) / 8); e += blockDim.x)
+        reinterpret_cast<uint64_t *>(s_tabs)[e] = reinterpret_cast<const uint64_t *>(tabs)[e];
     const bool prefix_in_lds = n_jobs + 1 <= BUILD_PREFIX_LDS;
-    if (prefix_in_lds) {
+    if (prefix_in_lds)
         for (int e = threadIdx.x; e <= n_jobs; e += blockDim.x) s_prefix[e] = prefix[e];
-        __syncthreads();
-    }
+    __syncthreads();
     if (pot < n_pot) {
         int lo = 0, hi = n_jobs;  // job = largest j with prefix[j] <= pot
         if (prefix_in_lds) {
@@ -468,7 +486,11 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const JobRec jr = jobs[job];
         const int o = jr.o;  // orientation of the job: which pair of layouts it runs on
         // swap: the lane tiles come from the first catalogue of the job (the binned one), the windows from the second
+#if defined(YAW_BUILD_TABS_GLOBAL)  // (A/B: the records read from the table in global memory, as before)
         const DevTab &c1 = tabs[swap ? 3 + o : o], &c2 = tabs[swap ? o : 3 + o];
+#else
+        const DevTab &c1 = s_tabs[swap ? 3 + o : o], &c2 = s_tabs[swap ? o : 3 + o];
+#endif
         const gf64p key1d = tab_key(c1), key2 = tab_key(c2);
         const gf32p key1f = c1.axis == 0 ? c1.qx : (c1.axis == 1 ? c1.qy : c1.qz);
         auto key1 = [&](int64_t i) { return triple ? (double)key1f[i] : key1d[i]; };
@@ -554,7 +576,7 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         }
         keep = it.nwin > 0;
     }
-    append_items(keep, it, work, items, counters, kept);
+    append_items(keep, it, work, items, counters, kept, seg_cap);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1586,16 +1608,34 @@ __global__ __launch_bounds__(64) void k_count_band(const DevTab *__restrict__ ta
 // (windows that reach a few lanes only) -- so eight contiguous eighths would give six XCDs the heavy items and two the light
 // ones. The list is cut into BLOCKS of 2^bs consecutive items (consecutive items are neighbouring lane tiles: their windows
 // overlap, which is what an XCD's L2 is for) and the blocks are dealt round robin to the XCDs.
+// A list the builder kept in segments (append_items, seg_cap > 0) needs none of this: XCD x takes segment x.
 struct TicketMap {
     unsigned long long per_xcd;  // tickets an XCD walks through (multiple of the block size)
+    unsigned long long n_kept;   // tickets below this are items (segmented: end of this XCD's segment)
+    unsigned long long seg_base; // segmented: first record of this XCD's segment
     unsigned bs;                 // log2 of the block size
+    bool segmented;
     __device__ __forceinline__ unsigned long long ticket(unsigned long long v) const {
         const unsigned long long j = v >> 3;
+        if (segmented) return seg_base + j;
         return ((((j >> bs) << 3) + (v & 7)) << bs) + (j & ((1ull << bs) - 1ull));
     }
 };
-__device__ __forceinline__ TicketMap ticket_map(unsigned long long n_kept) {
+__device__ __forceinline__ TicketMap ticket_map(const unsigned long long *__restrict__ counters, unsigned long long seg_cap) {
     TicketMap m;
+    m.segmented = seg_cap != 0;
+    if (m.segmented) {  // (gridDim.x is a multiple of 8: a workgroup stays with its XCD)
+        const int seg = (int)(blockIdx.x % ITEM_SEGS);
+        const unsigned long long n_seg = counters[ITEM_SEG_CTR(seg)];
+        m.seg_base = (unsigned long long)seg * seg_cap;
+        m.per_xcd = n_seg;
+        m.n_kept = m.seg_base + n_seg;
+        m.bs = 0;
+        return m;
+    }
+    const unsigned long long n_kept = counters[0];
+    m.n_kept = n_kept;
+    m.seg_base = 0;
     const unsigned long long want = n_kept >> 7;  // ~16 blocks per XCD
     int bs = want > 1 ? 63 - __builtin_clzll(want) : 0;
     bs = bs < 6 ? 6 : (bs > 12 ? 12 : bs);
@@ -1662,7 +1702,7 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
                                                      const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
                                                      unsigned long long *__restrict__ out_counts,
                                                      double *__restrict__ partials,
-                                                     unsigned long long *__restrict__ counters) {
+                                                     unsigned long long *__restrict__ counters, unsigned long long seg_cap) {
     static_assert(NE >= 2 && NE <= 4, "edges per bin");
     static_assert(CAP % 4 == 0, "stage capacity");
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
@@ -1685,8 +1725,8 @@ __global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 &
     const unsigned a_sw = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
     const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
 
-    const unsigned long long n_kept = counters[0];
-    const TicketMap tmap = ticket_map(n_kept);
+    const TicketMap tmap = ticket_map(counters, seg_cap);
+    const unsigned long long n_kept = tmap.n_kept;
     for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
     if (LANE_THR)
         for (int e = lane; e < n_bins * TW; e += 64) sthr[e] = thr32[e];
@@ -2132,7 +2172,7 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                                                           const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
                                                           unsigned long long *__restrict__ out_counts,
                                                           double *__restrict__ partials,
-                                                          unsigned long long *__restrict__ counters) {
+                                                          unsigned long long *__restrict__ counters, unsigned long long seg_cap) {
     using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
     constexpr int HB = WEIGHTED ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -2155,8 +2195,8 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
     const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
     const unsigned a_dummy = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(dummy + lane);
 
-    const unsigned long long n_kept = counters[0];
-    const TicketMap tmap = ticket_map(n_kept);
+    const TicketMap tmap = ticket_map(counters, seg_cap);
+    const unsigned long long n_kept = tmap.n_kept;
     for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
     for (int e = lane; e < rows * tw; e += 64) stab[e] = fine32[e];
     unsigned stage_no = 0;
@@ -2599,6 +2639,7 @@ struct yawhip_ctx {
                              // 1, 2, 4 and 8 measure the same at the headline)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
+    int item_segments = 1;   // strip builder -> float32 band kernels: the item list in eight segments, one per XCD (append_items)
     int triple_runs = 1;     // float32 band kernels stream merged triple runs (k_merge_triples) when the partner strips are c - 1, c, c + 1
     int band_fp32 = 1;       // band kernel on strip layouts of unit vectors: float32 classification + exact float64 for the
                              // guard bands (k_count_band32); 0: every entry in float64 (k_count_band)
@@ -3259,6 +3300,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         ctx->triple_runs = (int)value;
         return YAWHIP_OK;
     }
+    if (!strcmp(key, "item_segments")) {
+        ctx->item_segments = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "spin_wait")) {
         ctx->spin_wait = value != 0;
         return YAWHIP_OK;
@@ -3486,6 +3531,7 @@ struct CallState {
     int64_t n_out = 0;
     size_t o_ctr = 0, o_counts = 0, o_sums = 0;
     bool want_counts = false, want_sums = false, band_ran = false, run_unweighted = false, run_weighted = false;
+    bool segmented = false;        // the item list was kept in segments: the kept items are the sum of the segment counters
     int64_t cand = 0, abytes = 0, n_pot = 0;
     int launches = 0, kernel = 0, mode = 0, n_orient = 0, band_variant = 0, merged_triples = 0;
 };
@@ -4024,25 +4070,29 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     auto lds_for = [&](bool w, bool priv) { return lds_fixed + (size_t)nf * (priv ? WG : 1) * (w ? 8 : 4); };
     int launches = 0;
     const int64_t n_pot = n_items;  // potential items; the builder may drop some (SWEEP)
+    unsigned long long seg_cap = 0;  // > 0: the item list is kept in ITEM_SEGS segments of this many records
     g_trace.mark("memset");
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (n_pot > 0) {
         if (n_pot >= (1ll << 31))
             return fail(YAWHIP_ERR_INVALID, "too many work items (%lld) in one job", (long long)n_pot);
-        HIP_TRY(ctx->d_items.reserve((size_t)n_pot));
+        const int bwg = build_wg_for(n_pot);
+        const unsigned bgrid = (unsigned)((n_pot + bwg - 1) / bwg);
+        // item list in segments (append_items): where the float32 band kernels consume what the strip builder keeps
+        if (strip_items && (band32 || band_fine) && !job_work && ctx->item_segments)
+            seg_cap = (unsigned long long)((bgrid + ITEM_SEGS - 1) / ITEM_SEGS) * (unsigned long long)bwg;
+        HIP_TRY(ctx->d_items.reserve(seg_cap ? (size_t)(seg_cap * ITEM_SEGS) : (size_t)n_pot));
         unsigned char *kept_flags = nullptr;  // weighted runs of the culling builders: which potential items write a slab
         if (run_weighted && sweep) {
             HIP_TRY(ctx->d_kept.reserve((size_t)n_pot));
             HIP_TRY(hipMemsetAsync(ctx->d_kept.ptr, 0, (size_t)n_pot, ctx->stream));
             kept_flags = ctx->d_kept.ptr;
         }
-        const int bwg = build_wg_for(n_pot);
-        const unsigned bgrid = (unsigned)((n_pot + bwg - 1) / bwg);
         if (strip_items)
             hipLaunchKernelGGL(k_build_items_strips, dim3(bgrid), dim3(bwg), 0, ctx->stream, ctx->d_tabs.ptr,
                                reinterpret_cast<const JobRec *>(ctx->d_jobs.ptr), ctx->d_prefix.ptr, (int)n_sjobs,
                                triple ? 0 : reach, (int)tile, rwin_max, swap ? 1 : 0, triple ? 1 : 0, n_pot, ctx->d_items.ptr,
-                               ctx->d_ctr.ptr, kept_flags);
+                               ctx->d_ctr.ptr, kept_flags, seg_cap);
         else if (sweep)
             hipLaunchKernelGGL(k_build_items<true>, dim3(bgrid), dim3(bwg), 0, ctx->stream, view_of(c1), view_of(c2),
                                ctx->d_jobs.ptr, ctx->d_prefix.ptr, (int)n_pslots, n_bins, (int)tile,
@@ -4135,7 +4185,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band32, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
                            n_bins, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, swap ? 1 : 0, ctx->d_counts.ptr, \
-                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr, seg_cap);                                             \
     } while (0)
 #define YAW_LAUNCH_B32_R(WW, NN, MM, UU)                                                                              \
     do {                                                                                                              \
@@ -4212,7 +4262,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         }                                                                                                             \
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_fine, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
                            n_bins, n_edges, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, swap ? 1 : 0, ctx->d_counts.ptr, \
-                           ctx->d_partials.ptr, ctx->d_ctr.ptr);                                                      \
+                           ctx->d_partials.ptr, ctx->d_ctr.ptr, seg_cap);                                             \
     } while (0)
 #define YAW_LAUNCH_FINE_R(WW, MM, UU)                                                                                 \
     do {                                                                                                              \
@@ -4331,7 +4381,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     cs.pending = true;
     cs.o_ctr = o_ctr; cs.o_counts = o_counts; cs.o_sums = o_sums;
     cs.band_ran = band_ran; cs.run_unweighted = run_unweighted; cs.run_weighted = run_weighted;
-    cs.cand = cand; cs.abytes = abytes; cs.n_pot = n_pot;
+    cs.cand = cand; cs.abytes = abytes; cs.n_pot = n_pot; cs.segmented = seg_cap != 0;
     cs.launches = launches; cs.kernel = kernel; cs.mode = mode;
     cs.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
     cs.band_variant = !band_ran ? 0 : (band32 ? 32 : (band_fine ? 33 : 64));
@@ -4404,6 +4454,8 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         }
         stats->algorithmic_bytes = cs.abytes;
         stats->n_workgroups = cs.n_pot > 0 ? (int64_t)ctr[0] : 0;
+        if (cs.segmented && cs.n_pot > 0)
+            for (int sg = 0; sg < ITEM_SEGS; ++sg) stats->n_workgroups += (int64_t)ctr[ITEM_SEG_CTR(sg)];
         stats->n_launches = cs.launches;
         stats->kernel_used = cs.kernel;
         stats->layout_mode = cs.mode;
