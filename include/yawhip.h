@@ -117,6 +117,14 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *   "band_fp32"         1 (default): on strip layouts of unit vectors the band kernel classifies every evaluation in float32
  *                       and decides the ones inside a guard band of an edge with the exact float64 predicate (same results);
  *                       0: every evaluation in float64
+ *   "triple_runs"       float32 band kernels: the streamed side is read from MERGED runs of three neighbouring strips (one
+ *                       window per work item instead of three) when the strip grid is as wide as the largest separation --
+ *                       1 (default): where the merged window still fits one LDS stage, 2: always, 0: never (same results)
+ *   "item_segments"     1 (default): the strip builder keeps its work items in eight segments, one per XCD, each with its
+ *                       own append counter; 0: one list, dealt to the XCDs in blocks (same results)
+ *   "band_grid_div"     band kernels: workgroups = potential work items / this (default 4, 1..64); the kernel loops over the rest
+ *   "spin_wait"         1 (default): the host waits for a call's results by polling the stream for the first 2 ms, then blocks;
+ *                       0: it blocks at once
  *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every
  *                       2^value stages (default 17: 128 lane objects x 192 entries x 2^17 < 2^32; tests lower it) */
 int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value);
