@@ -3817,6 +3817,11 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
                 return ((double)c->n / (double)runs) / std::max(extent, 1e-6);
             };
             const double d1 = per_u(c_strm, LS), d2 = per_u(c_lane, LL);
+            // binned x binned counts on per-(patch, bin) strip runs: runs are short (35 objects at 10 M, 350 at 100 M objects in
+            // 30 bins), bands a handful of entries -- ONE object per lane then evaluates its own band instead of the union of
+            // two (DD of config #4: 2.7e7 instead of 5.6e7 entries, 0.63 -> 0.41 ms; RR 3.74 -> 3.57), unless the streamed side
+            // is much the sparser one and items are all fixed cost (DR: 2.05e6 items instead of 1.28e6, 1.86 -> 2.25 ms)
+            if (mode == 3 && d1 >= 0.5 * d2) R = 1;
             est_window = 64.0 * R * d1 / std::max(d2, 1e-12) + 2.0 * rwin_max * d1;
         }
     }
