@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 SOURCES = [os.path.join(CSRC, "yawhip.hip"), os.path.join(CSRC, "yawhip_sort.hip")]
-HEADERS = [os.path.join(ROOT, "include", "yawhip.h"), os.path.join(CSRC, "yawhip_sort.h")]
+HEADERS = [os.path.join(ROOT, "include", "yawhip.h"), os.path.join(CSRC, "yawhip_sort.h"), os.path.join(CSRC, "yawhip_band32.inc")]
 SRC = SOURCES[0]
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG_DIR, "libyawhip.so")

@@ -1221,6 +1221,17 @@ __device__ __forceinline__ int wave_max_nonneg(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Sum of an unsigned int over the 64 lanes, in lane 63 (same DPP steps; lanes without a source add 0).
+__device__ __forceinline__ unsigned int wave_sum_lane63(unsigned int v) {
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // NE: edges per bin known at compile time (2: one fine bin; 3, 4: edges in registers when every bin -- or the item -- has one
 // row of them); 0: any number, edge table in LDS.
 template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
@@ -1694,454 +1705,21 @@ __device__ __attribute__((noinline)) ExactEval<NT> band32_exact(gf64p lx, gf64p 
 // a CU holds). The big one is for lane tiles whose single window would not fit (denser streamed side, four objects per lane).
 constexpr int B32_CAP = YAW_B32_CAP;
 constexpr int B32_CAP_BIG = YAW_B32_CAP_BIG;
-constexpr int B32_MAX_CHUNKS = 3;  // windows (or pieces of one) staged together in one round of k_count_band32
+// The kernel itself: csrc/yawhip_band32.inc, compiled twice -- k_count_band32 stages up to three windows (or pieces of one)
+// in a round, k_count_band32_one a single one, for calls whose items all have one window (merged triple runs, items of
+// k_build_items): the bookkeeping of two more chunks costs scalar registers (spilled) and instructions per item, 0.283 against
+// 0.274 ms at the headline.
 
-template <int R, int CAP, bool WEIGHTED, int NE, bool MERGED, bool UNI>
-__global__ __launch_bounds__(64, (YAW_B32_WAVES > 1 ? YAW_B32_WAVES : (NE == 2 && UNI ? (WEIGHTED ? YAW_B32_WAVES_W : (CAP >= YAW_B32_CAP_BIG ? YAW_B32_WAVES_BIG : 7)) : (NE == 2 && !WEIGHTED ? YAW_B32_WAVES_LT : 1)))) void k_count_band32(const DevTab *__restrict__ tabs, const Item *__restrict__ items, int n_bins,
-                                                     const double *__restrict__ t, const float *__restrict__ thr32,
-                                                     const double *__restrict__ rwin_k, unsigned flush_mask, int swap,
-                                                     unsigned long long *__restrict__ out_counts,
-                                                     double *__restrict__ partials,
-                                                     unsigned long long *__restrict__ counters, unsigned long long seg_cap) {
-    static_assert(NE >= 2 && NE <= 4, "edges per bin");
-    static_assert(CAP % 4 == 0, "stage capacity");
-    using HistT = typename std::conditional<WEIGHTED, double, unsigned int>::type;
-    constexpr int NC = NE == 2 ? 1 : NE;     // counters per lane object: hits of the annulus, or s <= t_e per edge
-    constexpr int NF = NE - 1;               // fine bins per redshift bin
-    constexpr int TW = thr32_width(NE);
-    constexpr bool LANE_THR = MERGED && !UNI;  // every lane object has the edge row of its own bin
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
-    const int nkb = MERGED ? n_bins : 1;
-    const int nslots = nkb * NF;
-    unsigned char *p = lds_dyn;
-    constexpr unsigned COLB = (CAP + 4) * 4;  // bytes of one staged float32 column
-    float *stage = reinterpret_cast<float *>(p); p += (size_t)3 * COLB;  // columns x, y, z
-    double *sw = reinterpret_cast<double *>(p); if (WEIGHTED) p += (size_t)(CAP + 4) * 8;
-    HistT *hist = reinterpret_cast<HistT *>(p); p += (size_t)nslots * sizeof(HistT);
-    p = reinterpret_cast<unsigned char *>(((size_t)p + 15) & ~(size_t)15);
-    float *sthr = reinterpret_cast<float *>(p);  // [n_bins][TW] when LANE_THR
-    const int lane = threadIdx.x;
-    const unsigned a_stage = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(stage);
-    const unsigned a_sw = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(sw);
-    const unsigned a_hist = (unsigned)(size_t)(lds_byte *)reinterpret_cast<unsigned char *>(hist);
-
-    const TicketMap tmap = ticket_map(counters, seg_cap);
-    const unsigned long long n_kept = tmap.n_kept;
-    for (int e = lane; e < nslots; e += 64) hist[e] = HistT(0);  // every flush leaves the histogram zeroed again
-    if (LANE_THR)
-        for (int e = lane; e < n_bins * TW; e += 64) sthr[e] = thr32[e];
-    unsigned round_no = 0;
-    for (unsigned long long v = blockIdx.x;; v += gridDim.x) {
-        if ((v >> 3) >= tmap.per_xcd) break;
-        const unsigned long long ticket = tmap.ticket(v);
-        if (ticket >= n_kept) continue;  // beyond the last block's end
-        const Item it = items[ticket];
-        const int o = item_orient(it), islot = item_slot(it);
-        const DevTab cl = tabs[swap ? o : 3 + o], cs = tabs[swap ? 3 + o : o];  // lane side, streamed side
-        const int kfix = MERGED ? 0 : islot % n_bins;
-        // half width of the u-window in float32: sqrt(t_max) widened by the rounding of both keys and of the subtraction
-        const float rwin = (float)(rwin_k[kfix] * 1.000001 + 4e-7);
-
-        // The windows of an item are staged in ROUNDS: as many whole windows as fit the stage together (all three of a
-        // typical item: one wait for the LDS-DMA instead of three, and the band searches of the windows run in lockstep);
-        // a window longer than the stage goes through it alone, CAP - 4 entries at a time. A chunk = (first streamed
-        // object, entries, first entry of the stage it occupies); every chunk is followed by its own sentinel entry.
-        int win = 0;            // next window of the item
-        int64_t win_off = 0;    // entries of it already staged
-        int64_t cb[B32_MAX_CHUNKS];
-        int cn[B32_MAX_CHUNKS], co[B32_MAX_CHUNKS];
-        int nch = 0;
-        auto next_round = [&]() {
-            nch = 0;
-            int used = 0;
-#pragma unroll
-            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
-                cb[c] = 0; cn[c] = 0; co[c] = 0;
-                if (win < it.nwin && nch == c) {
-                    const int64_t wb = win == 0 ? it.b0[0] : (win == 1 ? it.b0[1] : it.b0[2]);
-                    const int64_t rem = (int64_t)(win == 0 ? it.nb[0] : (win == 1 ? it.nb[1] : it.nb[2])) - win_off;
-                    if (rem + 1 <= (int64_t)(CAP - used)) {           // the rest of the window and its sentinel fit
-                        cb[c] = wb + win_off; cn[c] = (int)rem; co[c] = used;
-                        used += ((int)rem + 1 + 3) & ~3;
-                        ++win; win_off = 0; ++nch;
-                    } else if (c == 0) {                               // alone in the stage, a piece at a time
-                        cb[c] = wb + win_off; cn[c] = CAP - 4; co[c] = 0;
-                        used = CAP;
-                        win_off += CAP - 4; ++nch;
-                    }
-                }
-            }
-        };
-        auto issue_round = [&]() {
-#pragma unroll
-            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
-                if (c < nch) {
-                    // four entries of one column per lane and instruction (16 bytes; the last lane may run up to three entries
-                    // past the chunk: into the next run of the catalogue, and into the chunk's padding in LDS)
-                    const gf32p gx = cs.qx + cb[c], gy = cs.qy + cb[c], gz = cs.qz + cb[c];
-                    const unsigned a_c = a_stage + ((unsigned)co[c] << 2);
-#pragma unroll
-                    for (int k = 0; k < (CAP + 255) / 256; ++k) {
-                        const unsigned e = (unsigned)(k * 256 + 4 * lane);
-                        if (e < (unsigned)cn[c]) {
-                            __builtin_amdgcn_global_load_lds(gx + e, lds_ptr(a_c + k * 1024), 16, 0, 0);
-                            __builtin_amdgcn_global_load_lds(gy + e, lds_ptr(a_c + COLB + k * 1024), 16, 0, 0);
-                            __builtin_amdgcn_global_load_lds(gz + e, lds_ptr(a_c + 2 * COLB + k * 1024), 16, 0, 0);
-                        }
-                    }
-                    if (WEIGHTED && cs.w) {
-#pragma unroll
-                        for (int k = 0; k < (CAP + 127) / 128; ++k) {
-                            const unsigned e = (unsigned)(k * 128 + 2 * lane);
-                            if (e < (unsigned)cn[c])
-                                __builtin_amdgcn_global_load_lds(cs.w + cb[c] + e, lds_ptr(a_sw + ((unsigned)co[c] << 3) + k * 1024), 16, 0, 0);
-                        }
-                    }
-                }
-            }
-        };
-        __syncthreads();  // the previous item of this workgroup has left the LDS
-        next_round();
-        issue_round();
-        // lane objects while the stage is in flight: R NEIGHBOURING objects of the u-sorted tile per lane
-        f32x2 ax2[R / 2 > 0 ? R / 2 : 1], ay2[R / 2 > 0 ? R / 2 : 1], az2[R / 2 > 0 ? R / 2 : 1];  // packed pairs (R even)
-        float ax[R], ay[R], az[R];
-        int kb[R];
-        int lane_obj = lane;  // whose objects this lane counts for: its own, until the bands of a sparse item are shared out
-        int n_own = (int)it.na - lane * R;
-        n_own = n_own < 0 ? 0 : (n_own > R ? R : n_own);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool have = r < n_own;
-            const unsigned ic = have ? (unsigned)(lane * R + r) : 0u;
-            ax[r] = have ? (cl.qx + it.a0)[ic] : PAD_COORD32;
-            ay[r] = have ? (cl.qy + it.a0)[ic] : PAD_COORD32;
-            az[r] = have ? (cl.qz + it.a0)[ic] : PAD_COORD32;
-            kb[r] = MERGED ? (have ? (cl.k + it.a0)[ic] : 0) : 0;
-        }
-        // thresholds: per lane object (its bin's row from the LDS table) or one row for the wave
-        float th[R][TW];
-        {
-            const float *row = LANE_THR ? nullptr : thr32 + (size_t)kfix * TW;  // uniform: scalar loads
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-                for (int q = 0; q < TW; ++q) th[r][q] = LANE_THR ? sthr[kb[r] * TW + q] : row[q];
-        }
-        float klo, khi;
-        {
-            const int last_r = n_own > 0 ? n_own - 1 : 0;
-            float u_first = cl.axis == 0 ? ax[0] : (cl.axis == 1 ? ay[0] : az[0]), u_last = u_first;
-#pragma unroll
-            for (int r = 1; r < R; ++r)
-                if (r == last_r) u_last = cl.axis == 0 ? ax[r] : (cl.axis == 1 ? ay[r] : az[r]);
-            klo = u_first - rwin;
-            khi = u_last + rwin;
-        }
-        if constexpr (R >= 2) {
-#pragma unroll
-            for (int h = 0; h < R / 2; ++h) {
-                ax2[h] = f32x2{ax[2 * h], ax[2 * h + 1]}; ay2[h] = f32x2{ay[2 * h], ay[2 * h + 1]}; az2[h] = f32x2{az[2 * h], az[2 * h + 1]};
-            }
-        }
-        f32x2 nc2[R / 2 > 0 ? R / 2 : 1];  // one annulus: -c of the lane's objects, the addend of the first product
-#pragma unroll
-        for (int h = 0; h < R / 2; ++h) nc2[h] = f32x2{-th[2 * h][0], -th[2 * h + 1][0]};
-        unsigned int cnt[R][NC];
-        double acc[R][NC];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { cnt[r][c] = 0u; acc[r][c] = 0.0; }
-        unsigned int nev = 0;
-        // lane counters -> LDS histogram (cell = bin of the object x fine bin)
-        auto flush_lanes = [&]() {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const unsigned cell = a_hist + (unsigned)((kb[r] * NF + f) * (int)sizeof(HistT));
-                    if constexpr (WEIGHTED) {
-                        const double vsum = NE == 2 ? acc[r][0] : acc[r][f + 1] - acc[r][f];
-                        // float64 adds of ONE instruction that hit the same cell are serialised by the LDS in a fixed lane
-                        // order; the histogram belongs to this wave alone -> reproducible sums
-                        // (the object's own weight is fetched here, once per item, instead of living in registers through the walk)
-                        const double aw = (cl.w && r < n_own) ? (cl.w + it.a0)[lane_obj * R + r] : 1.0;
-                        if (vsum != 0.0)
-                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(size_t)cell, aw * vsum,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    } else {
-                        const unsigned int c = NE == 2 ? cnt[r][0] : cnt[r][f + 1] - cnt[r][f];
-                        if (c)
-                            (void)__hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned int *)(size_t)cell, c,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { cnt[r][c] = 0u; acc[r][c] = 0.0; }
-            }
-        };
-        auto flush_counts = [&]() {  // LDS histogram -> global result (unweighted)
-            flush_lanes();
-            __syncthreads();
-            for (int idx = lane; idx < nslots; idx += 64) {
-                const unsigned int c = (unsigned int)hist[idx];
-                hist[idx] = HistT(0);
-                if (c) atomicAdd(&out_counts[(int64_t)islot * nslots + idx], (unsigned long long)c);
-            }
-        };
-
-        const bool single_window = it.nwin == 1 && it.nb[0] + 1 <= CAP;  // the item is this one chunk (see YAW_B32_SHARE)
-        for (;; ++round_no) {
-            // The round has landed: nothing but the issuing wave's own vmcnt orders an LDS read behind a pending LDS-DMA. The
-            // wait is spelled out -- in a single-wave workgroup __syncthreads() is no barrier instruction, and on this loop's
-            // back edge hipcc did not put a vmcnt wait in front of the LDS accesses by itself (counts came out wrong now and then).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (lane < nch) {  // a sentinel behind every chunk: beyond every edge of every lane object
-                const int at = (lane == 0 ? co[0] + cn[0] : (lane == 1 ? co[1] + cn[1] : co[2] + cn[2]));
-                stage[at] = PAD_COORD32; stage[COLB / 4 + at] = PAD_COORD32; stage[2 * (COLB / 4) + at] = PAD_COORD32;
-                if (WEIGHTED) sw[at] = 0.0;
-            }
-            if (WEIGHTED && !cs.w) {
-#pragma unroll
-                for (int c = 0; c < B32_MAX_CHUNKS; ++c)
-                    if (c < nch)
-                        for (int e = lane; e < cn[c]; e += 64) sw[co[c] + e] = 1.0;
-            }
-            __syncthreads();
-            // bands of the lane inside the chunks: [lo, hi) = entries with klo <= key <= khi, by branch-free binary searches
-            // on LDS byte addresses, all chunks in lockstep (q = address of entry lo - 1; a probe beyond a chunk is clamped
-            // onto its sentinel, whose key 4.0 fails both comparisons -- so one step schedule serves chunks of any length)
-            unsigned a_key[B32_MAX_CHUNKS], a_sent[B32_MAX_CHUNKS], ql[B32_MAX_CHUNKS], qh[B32_MAX_CHUNKS];
-            int n_max = 1;
-#pragma unroll
-            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
-                a_key[c] = a_stage + COLB * (unsigned)cl.axis + ((unsigned)co[c] << 2);
-                a_sent[c] = a_key[c] + ((unsigned)cn[c] << 2);
-                ql[c] = qh[c] = a_key[c] - 4u;
-                n_max = cn[c] > n_max ? cn[c] : n_max;
-            }
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 2
-            for (unsigned step = 0; step >= 4u; step >>= 1) {  // diagnostics: no search either
-#else
-            for (unsigned step = 4u << (31 - __builtin_clz(n_max)); step >= 4u; step >>= 1) {  // largest power of two <= n_max
-#endif
-#pragma unroll
-                for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
-                    if (c < nch) {
-                        const unsigned pl = ql[c] + step, ph = qh[c] + step;
-                        const float kl = *(const __attribute__((address_space(3))) float *)(size_t)(pl < a_sent[c] ? pl : a_sent[c]);
-                        const float kh = *(const __attribute__((address_space(3))) float *)(size_t)(ph < a_sent[c] ? ph : a_sent[c]);
-                        ql[c] = kl < klo ? pl : ql[c];    // entries [0, lo) have key <  klo
-                        qh[c] = kh <= khi ? ph : qh[c];   // entries [0, hi) have key <= khi
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < B32_MAX_CHUNKS; ++c) {
-            if (c < nch) {
-            const int n = cn[c];
-            int lo = (int)((ql[c] + 4u - a_key[c]) >> 2), hi = (int)((qh[c] + 4u - a_key[c]) >> 2);
-            if (n_own == 0) lo = hi = n;  // lanes without an object walk the sentinel
-            int len = hi - lo;
-            unsigned stride = 4u;  // bytes between the entries a lane evaluates (wave-uniform)
-#if !defined(YAW_BAND_DIAG) || YAW_BAND_DIAG != 3
-            nev += (unsigned int)(len * n_own);
-#endif
-#if YAW_B32_SHARE
-            // Sparse items -- a lane tile at the border of its patch whose partner run reaches only a few of its objects, the
-            // short last tile of a run: the walk takes as many trips as the longest band however few lanes have one (a seventh
-            // of all trips at the headline belonged to windows with bands in at most 32 lanes). When the lanes with a band
-            // span at most half the wave, their bands are SHARED OUT: 2, 4 or 8 lanes take the objects of one lane (register
-            // shuffles) and every 2nd, 4th or 8th entry of its band each. Counters and bins travel with the objects, so this is done only where the
-            // item consists of this one window (the lane counters are still zero and are flushed with the new owners).
-            if (single_window) {
-                const unsigned long long act = __builtin_amdgcn_ballot_w64(len > 0);
-                const int first = act ? __builtin_ctzll(act) : 0, span = act ? 64 - __builtin_clzll(act) - first : 64;
-                if (span <= 32) {
-                    const int sh = span <= 8 ? 3 : (span <= 16 ? 2 : 1);
-                    const bool idle = (lane >> sh) >= span;  // groups beyond the lanes that have a band: nothing to take
-                    const int src = idle ? first : first + (lane >> sh);
-                    const int part = lane & ((1 << sh) - 1);
-                    if constexpr (R >= 2) {
-#pragma unroll
-                        for (int h = 0; h < R / 2; ++h) {
-                            ax2[h] = f32x2{__shfl(ax2[h].x, src, 64), __shfl(ax2[h].y, src, 64)};
-                            ay2[h] = f32x2{__shfl(ay2[h].x, src, 64), __shfl(ay2[h].y, src, 64)};
-                            az2[h] = f32x2{__shfl(az2[h].x, src, 64), __shfl(az2[h].y, src, 64)};
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if constexpr (R < 2) { ax[r] = __shfl(ax[r], src, 64); ay[r] = __shfl(ay[r], src, 64); az[r] = __shfl(az[r], src, 64); }
-                        if constexpr (MERGED) kb[r] = __shfl(kb[r], src, 64);
-                        if constexpr (LANE_THR) {
-#pragma unroll
-                            for (int q = 0; q < TW; ++q) th[r][q] = sthr[kb[r] * TW + q];
-                        }
-                    }
-                    if constexpr (LANE_THR && NE == 2) {
-#pragma unroll
-                        for (int h = 0; h < R / 2; ++h) nc2[h] = f32x2{-th[2 * h][0], -th[2 * h + 1][0]};
-                    }
-                    n_own = __shfl(n_own, src, 64);
-                    lane_obj = src;
-                    // lane `part` of a group takes the entries lo + part, lo + part + S, ... of the band: a lane that walks on
-                    // past its share (the trip count is the wave's) meets the entries of no other lane of its group, and beyond
-                    // the band entries that fail the predicate by themselves -- as on the ordinary walk
-                    const int lo_s = __shfl(lo, src, 64), len_s = __shfl(len, src, 64);
-                    lo = idle ? n : lo_s + part;  // (idle lanes walk the sentinel)
-                    len = !idle && len_s > part ? (len_s - part + (1 << sh) - 1) >> sh : 0;
-                    stride = 4u << sh;
-                }
-            }
-#endif
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG >= 1 && YAW_BAND_DIAG < 3
-            const int steps = 0;  // diagnostics: everything but the walk (wrong counts)
-#else
-            const int steps = wave_max_nonneg(len);  // the longest band of the wave: uniform trip count
-#endif
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 3
-#ifdef YAW_DIAG_ACT   // ... of the (item, window)s with at most YAW_DIAG_ACT lanes that have a band at all
-            int act = __popcll(__builtin_amdgcn_ballot_w64(len > 0));
-            asm volatile("" : "+s"(act));  // the ballot stays in front of the lane-0 branch
-            nev += lane == 0 && act <= YAW_DIAG_ACT ? (unsigned int)steps : 0u;
-#else
-            nev += lane == 0 ? (unsigned int)steps : 0u;  // diagnostics: "evaluated" reports the trips of the walk
-#endif
-#endif
-
-            const unsigned a_chunk = a_stage + ((unsigned)co[c] << 2);
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == 4
-            unsigned cur = a_chunk + ((unsigned)lane << 2);  // diagnostics: the walk without LDS bank conflicts (wrong counts)
-#else
-            unsigned cur = a_chunk + ((unsigned)lo << 2);
-#endif
-            const unsigned last = a_chunk + ((unsigned)n << 2);
-            // One entry per evaluation step: three 4-byte reads from columns a fixed distance apart (lanes read nearly
-            // consecutive words of a column). YAW_B32_UNROLL entries per trip of the loop: their LDS reads go out together and the
-            // loop's own instructions are shared (a trip past the end of the longest band meets entries beyond every band,
-            // or the sentinel: they fail the predicate by themselves).
-            auto eval_entry = [&](const unsigned a16) {
-                struct { float x, y, z; } en;
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -1
-                en.x = klo; en.y = khi; en.z = klo;  // diagnostics: the walk's arithmetic without its LDS reads (wrong counts)
-                asm volatile("" : "+v"(en.x), "+v"(en.y), "+v"(en.z));
-#else
-                en.x = *(const __attribute__((address_space(3))) float *)(size_t)a16;
-                en.y = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + COLB);
-                en.z = *(const __attribute__((address_space(3))) float *)(size_t)(a16 + 2 * COLB);
-#endif
-                const double ew = WEIGHTED ? lds_f64(((a16 - a_stage) << 1) + a_sw) : 1.0;
-#if defined(YAW_BAND_DIAG) && YAW_BAND_DIAG == -2
-                cnt[0][0] += __float_as_uint(en.x) ^ __float_as_uint(en.y) ^ __float_as_uint(en.z);  // diagnostics: the LDS reads alone
-                return;
-#endif
-                // One annulus: the centre c of the annulus is the addend of the first product, q = s32 - c comes out of the three
-                // fused multiply-adds (no subtraction per evaluation; the host widens both classes by the rounding of the
-                // intermediate sums, build_thr32). More edges: s32 itself.
-                float s32[R];
-                if constexpr (R >= 2) {
-#pragma unroll
-                    for (int h = 0; h < R / 2; ++h) {
-                        const f32x2 dx = ax2[h] - en.x, dy = ay2[h] - en.y, dz = az2[h] - en.z;
-                        f32x2 sq;
-                        if constexpr (NE == 2) sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, nc2[h])));
-                        else sq = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
-                        s32[2 * h] = sq.x; s32[2 * h + 1] = sq.y;
-                    }
-                } else {
-                    const float dx = ax[0] - en.x, dy = ay[0] - en.y, dz = az[0] - en.z;
-                    if constexpr (NE == 2) s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, -th[0][0])));
-                    else s32[0] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                }
-                // classes as wave masks: "certainly inside / below" feeds the lane counters (add with carry), "possibly" stays
-                // on the scalar unit -- undecided = possibly & ~certainly costs no vector instruction
-                unsigned long long unc_mask[R];
-                unsigned long long any_mask = 0ull;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if constexpr (NE == 2) {
-                        const float q = __builtin_fabsf(s32[r]);  // |s32 - c|
-                        const bool in = q < th[r][1];
-                        unc_mask[r] = __builtin_amdgcn_ballot_w64(q < th[r][2]) & ~__builtin_amdgcn_ballot_w64(in);
-                        // weighted: acc += w of the entry where inside -- as an fma with the multiplier 1.0 / 0.0 (exact: the same
-                        // rounding as the add; one select instead of two on the 64-bit operand)
-                        if constexpr (WEIGHTED) acc[r][0] = __builtin_fma(in ? 1.0 : 0.0, ew, acc[r][0]);
-                        else cnt[r][0] += in ? 1u : 0u;
-                    } else {
-                        unc_mask[r] = 0ull;
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) {
-                            const bool le = s32[r] < th[r][2 * e];  // certainly s <= t_e
-                            unc_mask[r] |= __builtin_amdgcn_ballot_w64(s32[r] <= th[r][2 * e + 1]) & ~__builtin_amdgcn_ballot_w64(le);
-                            if constexpr (WEIGHTED) acc[r][e] = __builtin_fma(le ? 1.0 : 0.0, ew, acc[r][e]);
-                            else cnt[r][e] += le ? 1u : 0u;
-                        }
-                    }
-                    any_mask |= unc_mask[r];
-                }
-                if (any_mask != 0ull) {
-                    // inside a guard band: the exact float64 predicate on the float64 columns decides (rare)
-                    const unsigned eidx = (a16 - a_chunk) >> 2;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if (((unc_mask[r] >> lane) & 1ull) && eidx < (unsigned)n && r < n_own) {
-                            const ExactEval<NE> ev = band32_exact<NE>(cl.x, cl.y, cl.z, it.a0 + lane_obj * R + r, cs.x, cs.y, cs.z,
-                                                                      cs.idx ? (int64_t)cs.idx[cb[c] + eidx] : cb[c] + (int64_t)eidx,
-                                                                      t + (size_t)(MERGED ? kb[r] : kfix) * NE,
-                                                                      counters + 9 + 8 * (ticket & (EVAL_SLOTS - 1)));
-                            const double sd = ev.s;
-                            if constexpr (NE == 2) {
-                                const bool in = sd > ev.th[0] && sd <= ev.th[1];
-                                if constexpr (WEIGHTED) acc[r][0] += in ? ew : 0.0;
-                                else cnt[r][0] += in ? 1u : 0u;
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < NE; ++e) {
-                                    const bool open = !(s32[r] < th[r][2 * e]) && s32[r] <= th[r][2 * e + 1];  // this edge was left undecided
-                                    const bool le = open && sd <= ev.th[e];
-                                    if constexpr (WEIGHTED) acc[r][e] += le ? ew : 0.0;
-                                    else cnt[r][e] += le ? 1u : 0u;
-                                }
-                            }
-                        }
-                    }
-                }
-            };
-            for (int s = 0; s < steps; s += YAW_B32_UNROLL) {
-#pragma unroll
-                for (int uu = 0; uu < YAW_B32_UNROLL; ++uu) {
-                    const unsigned at = cur + stride * (unsigned)uu;
-                    eval_entry(at < last ? at : last);
-                }
-                cur += stride * YAW_B32_UNROLL;
-            }
-            }
-            }
-            // a lane counter grows by at most one per trip, the LDS cell by 64 R per trip: flush before 2^32
-            if (!WEIGHTED && (round_no & flush_mask) == flush_mask) flush_counts();
-            if (win >= it.nwin) break;
-            __syncthreads();  // every lane is done with this round's stage
-            next_round();
-            issue_round();
-        }
-        ++round_no;
-        if constexpr (WEIGHTED) {
-            flush_lanes();
-            __syncthreads();
-            for (int idx = lane; idx < nslots; idx += 64) {
-                partials[(int64_t)it.pot * nslots + idx] = (double)hist[idx];
-                hist[idx] = HistT(0);
-            }
-        } else {
-            flush_counts();
-        }
-        for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
-        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
-    }
-}
+#define YAW_B32_NAME k_count_band32
+#define YAW_B32_CH 3
+#include "yawhip_band32.inc"
+#undef YAW_B32_NAME
+#undef YAW_B32_CH
+#define YAW_B32_NAME k_count_band32_one
+#define YAW_B32_CH 1
+#include "yawhip_band32.inc"
+#undef YAW_B32_NAME
+#undef YAW_B32_CH
 
 // ------------------------------------------------------------------------------------------------
 // Band kernel for FINE radial grids (separation weights: `resolution` + 1 log-spaced edges per redshift bin,
@@ -2455,8 +2033,8 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
         } else {
             flush_counts();
         }
-        for (int off = 32; off > 0; off >>= 1) nev += __shfl_down(nev, off, 64);
-        if (lane == 0 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
+        nev = wave_sum_lane63(nev);  // (DPP: the shuffle form is six trips through the LDS crossbar, per item, for a statistic)
+        if (lane == 63 && nev) atomicAdd(&counters[8 + 8 * (ticket & (EVAL_SLOTS - 1))], (unsigned long long)nev);
     }
 }
 
@@ -4179,10 +3757,11 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         while (flush_log2 > 0 && ((uint64_t)64 * R * cap << flush_log2) >= (1ull << 32)) --flush_log2;
         const unsigned flush_mask = (1u << flush_log2) - 1u;
         const size_t lds_band32 = band32_lds(weighted_any, cap, lean_bins * nf, merged && !uniform_t ? n_bins : 0, n_edges);
+        const bool one_chunk = triple || !strip_items;  // every item has one window
         auto launch_band32 = [&](bool wgt) -> hipError_t {
-#define YAW_LAUNCH_B32(RR, CC, WW, NN, MM, UU)                                                                        \
+#define YAW_LAUNCH_B32_CH(RR, CC, WW, NN, MM, UU, KNAME)                                                              \
     do {                                                                                                              \
-        auto kern = k_count_band32<RR, CC, WW, NN, MM, UU>;                                                           \
+        auto kern = KNAME<RR, CC, WW, NN, MM, UU>;                                                                    \
         if (lds_band32 > 64 * 1024) {                                                                                 \
             hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                 \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_band32);         \
@@ -4191,6 +3770,11 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds_band32, ctx->stream, ctx->d_tabs.ptr, ctx->d_items.ptr, \
                            n_bins, ctx->d_t.ptr, ctx->d_thr32.ptr, ctx->d_rwin.ptr, flush_mask, swap ? 1 : 0, ctx->d_counts.ptr, \
                            ctx->d_partials.ptr, ctx->d_ctr.ptr, seg_cap);                                             \
+    } while (0)
+#define YAW_LAUNCH_B32(RR, CC, WW, NN, MM, UU)                                                                        \
+    do {                                                                                                              \
+        if (one_chunk) YAW_LAUNCH_B32_CH(RR, CC, WW, NN, MM, UU, k_count_band32_one);                                 \
+        else YAW_LAUNCH_B32_CH(RR, CC, WW, NN, MM, UU, k_count_band32);                                               \
     } while (0)
 #define YAW_LAUNCH_B32_R(WW, NN, MM, UU)                                                                              \
     do {                                                                                                              \
@@ -4215,6 +3799,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
 #undef YAW_LAUNCH_B32_M
 #undef YAW_LAUNCH_B32_R
 #undef YAW_LAUNCH_B32
+#undef YAW_LAUNCH_B32_CH
             return hipGetLastError();
         };
         auto launch_band64 = [&](bool wgt) -> hipError_t {
