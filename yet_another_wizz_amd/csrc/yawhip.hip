@@ -1952,7 +1952,7 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                 }
                 int jj[R];
                 bool unc[R];
-                bool any_unc = false;
+                unsigned long long any_unc_mask = 0ull;
                 f32x2 tb[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -1972,10 +1972,12 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int j = jj[r];
-                    const bool below = s32[r] < tb[r].x;  // the side of the edge s32 lies on
+                    // the side of the edge s32 lies on; "inside the guard band of edge j" = neither below nor above (spelled
+                    // !below && !(s32 > hi) the compiler issues a third compare for the negation)
+                    const bool below = s32[r] < tb[r].x, above = s32[r] > tb[r].y;
                     const int bin = j - (below ? 1 : 0);
-                    unc[r] = !below && !(s32[r] > tb[r].y);  // inside the guard band of edge j
-                    any_unc |= unc[r];
+                    unc[r] = !(below | above);
+                    any_unc_mask |= ~(__builtin_amdgcn_ballot_w64(below) | __builtin_amdgcn_ballot_w64(above));  // scalar unit only
                     const bool hit = ((unsigned)bin < (unsigned)nf) & !unc[r];
                     const unsigned cell = a_rowh[r] + ((unsigned)bin << HB);
                     if constexpr (WEIGHTED) {
@@ -1987,9 +1989,9 @@ __global__ __launch_bounds__(64) void k_count_band32_fine(const DevTab *__restri
                     }
                 }
 #if defined(YAW_FINE_DIAG) && YAW_FINE_DIAG == 6
-                any_unc = false;  // diagnostics: no exact re-evaluation (wrong counts)
+                any_unc_mask = 0ull;  // diagnostics: no exact re-evaluation (wrong counts)
 #endif
-                if (__builtin_amdgcn_ballot_w64(any_unc) != 0ull) {
+                if (any_unc_mask != 0ull) {
                     // the exact float64 predicate on the float64 columns decides, against the host's float64 thresholds (rare)
                     const unsigned eidx = (a16 - a_stage) >> 2;
 #pragma unroll
