@@ -187,6 +187,53 @@ def test_sparse_items_share_their_bands(ctx, n1, weights):
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
 
 
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+def test_merged_triple_runs_and_item_segments(ctx, weights):
+    """The streamed side of a float32 band count read from MERGED runs of three neighbouring strips (k_merge_triples; one
+    window per item) or from the strips themselves (three windows), the item list in eight segments or in one: every
+    combination gives the oracle's counts. A strip grid as wide as the largest separation (reach 1) is what merging needs;
+    `triple_runs = 2` merges also where the merged window no longer fits the stage (it then goes through it in pieces), with
+    the small and the big stage; the dense unbinned side makes windows of several hundred entries."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(777)
+    P, B = 4, 3
+    c1 = _random_catalog(rng, 9000, P, B, weights[0] == "w", dense_box=3.0)
+    c2 = _random_catalog(rng, 60000, P, 1, weights[1] == "w", dense_box=3.0)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    arcmin = np.pi / 10800
+    lim = oracle.parse_ang_limits([1.0 * arcmin], [10.0 * arcmin])
+    t = np.tile(oracle.thresholds_for(oracle.ang_bins_for(lim, None, None)), (B, 1))
+    exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
+    exp_self, exp_self_s = oracle.count_jobs(c1, c1, jobs, t)
+    micro = int(np.sqrt(t.max()) * 1.02e6) + 1  # just above the largest chord: partners in the strips c - 1, c, c + 1
+    seen = set()
+    try:
+        ctx.set_option("strip_width_micro", micro)
+        d1, d2 = _upload(ctx, c1), _upload(ctx, c2)
+        for triple in (0, 1, 2):
+            ctx.set_option("triple_runs", triple)
+            for segments in (0, 1):
+                ctx.set_option("item_segments", segments)
+                for cap in (0, 320, 512):
+                    ctx.set_option("band_cap", cap)
+                    for (da, db, ec, es) in ((d1, d2, exp_c, exp_s), (d1, d1, exp_self, exp_self_s)):
+                        counts, sums, st = _lib.count_pairs(ctx, da, db, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                        assert st.kernel_used == _lib.KERNEL_BAND
+                        assert np.array_equal(counts, ec), (triple, segments, cap)
+                        if weights == "uu":
+                            assert np.array_equal(sums, ec.astype(np.float64))
+                        else:
+                            np.testing.assert_allclose(sums, es, rtol=RTOL_W, atol=0)
+                        if db is d2:
+                            assert st.band_variant == 32
+                            seen.add((triple, bool(st.merged_triples)))
+        assert (0, False) in seen and (2, True) in seen  # both forms of the streamed side ran
+    finally:
+        for key, value in (("triple_runs", 1), ("item_segments", 1), ("band_cap", 0), ("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)):
+            ctx.set_option(key, value)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_empty_and_degenerate(ctx, kernel):
     from yet_another_wizz_amd import _lib
