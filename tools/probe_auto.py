@@ -27,6 +27,9 @@ if os.environ.get("YAW_STRIP_MICRO"):
     engine.forced_strip_micro = int(os.environ["YAW_STRIP_MICRO"])
 if os.environ.get("YAW_TILE_R"):
     engine.get_context().set_option("tile_r", int(os.environ["YAW_TILE_R"]))
+for _opt in os.environ.get("YAW_SET", "").split(","):  # YAW_SET=key=value,key=value: any context option
+    if "=" in _opt:
+        engine.get_context().set_option(_opt.split("=")[0], int(_opt.split("=")[1]))
 if os.environ.get("YAW_BAND_CAP"):
     engine.get_context().set_option("band_cap", int(os.environ["YAW_BAND_CAP"]))
 config = yaw.Configuration.create(rmin=1.0, rmax=10.0, unit="arcmin", zmin=0.1, zmax=1.0, num_bins=30)
