@@ -86,7 +86,7 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
         os.remove(FLAGS_STAMP)  # no stamp while the build is incomplete
     hipcc = hipcc_path()
     newest_header = max(os.path.getmtime(p) for p in HEADERS)
-    objects = []
+    objects, running = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         objects.append(obj)
@@ -98,7 +98,10 @@ def build_library(force: bool = False, verbose: bool = False, extra_flags=()) ->
         cmd = [hipcc, *HIPCC_FLAGS, *flags, f"-I{INCLUDE}", f"-I{CSRC}", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        running.append((cmd, subprocess.Popen(cmd)))  # the translation units compile side by side
+    for cmd, proc in running:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objects]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
