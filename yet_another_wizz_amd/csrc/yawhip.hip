@@ -3409,15 +3409,17 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
     // Merged triple runs on the streamed side: one window per item instead of three (k_merge_triples), when the partner
     // strips are exactly c - 1, c, c + 1 (grid at least as wide as the largest separation) AND the merged window still goes
     // through the stage in one piece: cut in pieces it costs more than three whole windows (100M x 100M: 22.0 against 14.9 ms,
-    // 50M x 50M with three scales 25.8 against 17.9). Weighted runs and the fine-grid kernel have less room (a larger stage
-    // costs them residency: weighted headline 0.55 against 0.51 ms, 51 fine bins 1.40 against 1.15 in a 512-entry stage),
-    // so they merge only windows that fit the stage they use anyway (sparse streamed sides: DR of config #4 2.07 against 2.43).
+    // 50M x 50M with three scales 25.8 against 17.9). The fine-grid kernel has less room (a larger stage costs it residency:
+    // 51 fine bins 1.25 against 1.06 ms in a 512-entry stage), so it merges only windows that fit the stage it uses anyway
+    // (sparse streamed sides: DR of config #4 2.07 against 2.43). Weighted counts merge like unweighted ones since the kernel
+    // with one chunk per round exists: the count kernel takes the same 0.48 ms at the headline in the big stage, the builder
+    // searches one window per item instead of three (0.045 against 0.063 ms).
     bool triple = false;
     if ((band32 || band_fine) && strip_items && ctx->triple_runs && c_strm->n < (1ll << 31) && c1->strip_width > 0.0 &&
         (int)std::floor(rwin_max / c1->strip_width + 1e-6) + 1 == 1) {
         const double est3 = 3.0 * est_window;
         triple = ctx->triple_runs == 2 ||
-                 (band32 ? est3 <= (weighted_any ? 0.75 * (B32_CAP - 4) : 0.88 * (B32_CAP_BIG - 4)) : est3 <= 0.9 * BCAP_MID);
+                 (band32 ? est3 <= 0.88 * (B32_CAP_BIG - 4) : est3 <= 0.9 * BCAP_MID);
         for (int o = 0; o < 3 && triple; ++o) {
             if (!LS[o]) continue;
             const int rc = build_triples(ctx, const_cast<yawhip_catalog *>(c_strm), o, mode == 3);
