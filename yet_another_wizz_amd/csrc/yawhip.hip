@@ -172,6 +172,9 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_UNROLL
 #define YAW_B32_UNROLL 1  // entries per trip of the walk loop: 1, 2 and 4 measure the same (0.362 / 0.366 / 0.374 ms at the headline)
 #endif
+#ifndef YAW_B32_PAIRS
+#define YAW_B32_PAIRS 1  // k_count_band32_one with one object per lane evaluates two entries per trip (packed float32)
+#endif
 #ifndef YAW_B32_SHARE
 #define YAW_B32_SHARE 1  // bands of sparse single-window items are shared out over the wave (k_count_band32)
 #endif
