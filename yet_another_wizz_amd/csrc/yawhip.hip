@@ -14,16 +14,21 @@
 //     per object -- whose runs can be paired across catalogues by grid index alone;
 //   * k_build_items / k_build_items_strips turn the job table into work items (lane tile of c2) x (window of a
 //     c1 segment or run): one thread per potential item decodes it arithmetically, binary-searches the window
-//     |du| <= sqrt(t_max) and drops empty ones; one atomic per workgroup appends the rest;
+//     |du| <= sqrt(t_max) and drops empty ones; one atomic per workgroup appends the rest -- for the float32 band
+//     kernels into one of eight segments of the list, one per XCD (append_items);
 //   * k_count (EXACT / FILTER, non-unit input): 256-thread workgroups, 256*R lane objects in registers, the
 //     c1 segment streamed through LDS; 8 FP64 ops + compare per pair, or a conservative FP32 dot-product test
 //     first and exact FP64 for its survivors. Per-lane private LDS histograms, fixed-order reduction;
 //   * k_count_merged (SWEEP): single-wave workgroups, float32 only on chip (packed v_pk_fma_f32),
 //     survivors queued per wave and evaluated 64 at a time in exact FP64; one item of the cross-correlation
-//     path covers all redshift bins. AUTO uses it on layouts without strips and for sparse streamed runs;
-//   * k_count_band (BAND, what AUTO runs on strip layouts -- the headline): single-wave workgroups, the window of a
-//     lane tile staged in LDS by LDS-DMA, every lane walks only the band |du| <= r of its two neighbouring objects
-//     and decides every entry with the exact FP64 predicate (no pre-filter, no queue).
+//     path covers all redshift bins. AUTO uses it on layouts without strips;
+//   * k_count_band32 / k_count_band32_one (BAND, what AUTO runs on strip layouts of unit vectors -- the headline;
+//     csrc/yawhip_band32.inc): single-wave workgroups, the window of a lane tile staged in LDS by LDS-DMA from float32
+//     images of the columns, every lane walks only the band |du| <= r of its objects, classifies every entry in
+//     float32 against guard bands around the edges and decides the few inside a guard band with the exact FP64
+//     predicate on the float64 columns (results identical to an all-float64 evaluation). The streamed side is read
+//     from merged runs of three neighbouring strips (k_merge_triples) where such a window fits the stage;
+//     k_count_band32_fine: the same for fine radial grids (separation weights); k_count_band: every entry in FP64.
 // Unweighted counts: uint32 LDS histograms -> 64-bit integer atomics. Weighted sums: per-item slabs (LDS float64
 // atomics private to one wave) reduced in a fixed two-level order -> bit-reproducible run to run. No floating
 // point atomics in global memory.
