@@ -937,20 +937,27 @@ def test_windows_longer_than_the_stage(ctx, grid, weights):
             d2 = _lib.DeviceCatalog(ctx, c2["x"], c2["y"], c2["z"], c2["w"], 2, nb2, c2["off"])
             exp_c, exp_s = oracle.count_jobs(c1, c2, jobs, t)
             assert exp_c.sum() > 1e6
-            for log2 in (17, 0):
-                ctx.set_option("flush_stages_log2", log2)
-                counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band", want_counts=True, want_sums=True)
-                assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == (1 if nb2 == 1 else 3)
-                assert st.band_variant == (33 if grid == "fine" else 32)
-                assert np.array_equal(counts, exp_c), (nb2, log2)
-                if weights == "uu":
-                    assert np.array_equal(sums, exp_c.astype(np.float64))
-                else:
-                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+            # (objects per lane, merged triple runs): the library's choice; one / two objects per lane with the merged window --
+            # three times as long -- forced through the stage in pieces (one object per lane: two entries per trip of the walk)
+            for tile_r, triple in ((0, 1), (1, 2), (2, 2)):
+                ctx.set_option("tile_r", tile_r)
+                ctx.set_option("triple_runs", triple)
+                for log2 in (17, 0):
+                    ctx.set_option("flush_stages_log2", log2)
+                    counts, sums, st = _lib.count_pairs(ctx, d1, d2, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                    assert st.kernel_used == _lib.KERNEL_BAND and st.layout_mode == (1 if nb2 == 1 else 3)
+                    assert st.band_variant == (33 if grid == "fine" else 32)
+                    assert np.array_equal(counts, exp_c), (nb2, log2, tile_r, triple)
+                    if weights == "uu":
+                        assert np.array_equal(sums, exp_c.astype(np.float64))
+                    else:
+                        np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
     finally:
         ctx.set_option("strip_width_micro", _lib.DEFAULT_STRIP_MICRO)
         ctx.set_option("seg_strips_min_run", 16)
         ctx.set_option("flush_stages_log2", 17)
+        ctx.set_option("tile_r", 0)
+        ctx.set_option("triple_runs", 1)
 
 
 def test_band_kernel_flush_interval(ctx):
