@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 FP64_VECTOR_PEAK_TFLOPS = 78.6            # MI355X FP64 vector peak incl. FMA (AMD spec)
 FP32_VECTOR_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBPS = 8000.0                    # MI355X_MICROARCH.md: HBM3E 8 TB/s
+N_SIMDS = 1024                            # 256 CUs x 4 SIMDs
+SHADER_CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: peak engine clock
+WALK_VALU_PER_TRIP = 14                   # k_count_band32, one annulus, two objects per lane: vector instructions per trip
 
 
 def parse_args():
@@ -58,10 +61,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def traffic_key(args, kernel_name):
-    """Key of profiles/pmc_traffic.json: the whole workload, not just its size."""
-    return (f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}:p{args.patches}:b{args.zbins}:s{getattr(args, 'scales', 1)}"
-            f":w{int(bool(getattr(args, 'weights', False)))}")
+def traffic_key(args, kernel_name, band_variant=None):
+    """Key of profiles/pmc_traffic.json: the whole workload -- sizes, scales, weights, separation weights (``rw<resolution>``),
+    physical scales (``kpc``: per-bin thresholds, another kernel variant) -- and the band kernel variant that ran
+    (``stats.band_variant``), so that a line can only quote counters of its own kernel."""
+    key = (f"{kernel_name}:{int(args.n_ref)}x{int(args.n_unk)}:p{args.patches}:b{args.zbins}:s{getattr(args, 'scales', 1)}"
+           f":w{int(bool(getattr(args, 'weights', False)))}")
+    if getattr(args, "rweight", None) is not None:
+        key += ":rw50"   # make_catalogs: resolution=50
+    if getattr(args, "kpc", False):
+        key += ":kpc"
+    if band_variant:
+        key += f":v{int(band_variant)}"
+    return key
 
 
 # ---------------------------------------------------------------------------------------------- inputs
@@ -78,6 +90,22 @@ def uniform_sky(seed, n):
     (src/yaw/randoms.py:246-259) on the full sky. Radian."""
     rng = np.random.default_rng(seed)
     return rng.uniform(0.0, 2.0 * np.pi, n), np.arcsin(rng.uniform(-1.0, 1.0, n)), rng
+
+
+def box_sky(seed, n, width=60.0, height=30.0):
+    """BASELINE config #2's footprint: ra ~ U(0, width), dec = arcsin(U(0, sin height)) -- a box of
+    width x height degrees on the equator. DEGREES. The same recipe tools/time_reference.py --box feeds to the reference."""
+    rng = np.random.default_rng(seed)
+    ra = rng.uniform(0.0, width, n)
+    dec = np.rad2deg(np.arcsin(rng.uniform(0.0, np.sin(np.deg2rad(height)), n)))
+    return ra, dec, rng
+
+
+def box_centers(width=60.0, height=30.0, grid=4):
+    """Patch centres of the box: a regular grid x grid lattice. Radian, [grid * grid, 2]."""
+    ga = np.linspace(width / (2 * grid), width * (2 * grid - 1) / (2 * grid), grid)
+    gd = np.linspace(height / (2 * grid), height * (2 * grid - 1) / (2 * grid), grid)
+    return np.deg2rad(np.array([(a, d) for a in ga for d in gd]))
 
 
 def make_inputs(args):
@@ -176,11 +204,14 @@ def reference_timing(args):
     """The reference's OWN count_pairs on this workload, timed in the build container by tools/time_reference.py (the
     reference cannot travel to the GPU box): seconds and effective candidate pairs/s with its multiprocessing pool on all
     cores and on one core. None when no run of this configuration is committed."""
-    if getattr(args, "weights", False):
-        return None
-    name = {(10e6, 10e6, 64, 30, 1): "reference_cpu_10Mx10M.json",
-            (50e6, 50e6, 128, 30, 3): "reference_cpu_50Mx50M_3scales.json"}.get(
-        (float(args.n_ref), float(args.n_unk), args.patches, args.zbins, getattr(args, "scales", 1)))
+    if getattr(args, "kpc", False) or getattr(args, "rweight", None) is not None:
+        return None  # the reference was timed on angular scales without separation weights only
+    name = {(10e6, 10e6, 64, 30, 1, False): "reference_cpu_10Mx10M.json",
+            (10e6, 10e6, 64, 30, 1, True): "reference_cpu_10Mx10M_weighted.json",
+            (1e6, 1e6, 16, 30, 1, False): None,  # config #2 was timed on its 60 x 30 degree box (reference_cpu_1Mx1M_box.json), not on the full sky
+            (50e6, 50e6, 128, 30, 3, False): "reference_cpu_50Mx50M_3scales.json"}.get(
+        (float(args.n_ref), float(args.n_unk), args.patches, args.zbins, getattr(args, "scales", 1),
+         bool(getattr(args, "weights", False))))
     path = os.path.join(ROOT, "profiles", name) if name else None
     if not path or not os.path.exists(path):
         return None
@@ -219,6 +250,12 @@ def exact_sample(links, ref, unk, n_jobs=2):
                 note="8 non-FMA FP64 flop per candidate pair against half the FP64 vector peak (SURVEY.md 8(d))")
 
 
+def parallel_device():
+    from yet_another_wizz_amd import engine
+
+    return engine.get_context().device
+
+
 def scaling_probe(steps, warmup, barrier, dist, world, rank):
     """With N > 1 ranks the headline call (0.35 ms of count kernel, ~0.2 ms of fixed cost per call) is too short to show
     what N GPUs buy; the same run therefore also times BASELINE config #5 (50M x 50M, 128 patches, 3 log scales: ~18 ms of
@@ -237,15 +274,23 @@ def scaling_probe(steps, warmup, barrier, dist, world, rank):
     unk.build_trees(None)
     links = PatchLinkage.from_catalogs(config, ref, unk)
     setup_s = time.perf_counter() - t0
+    first_info = None
     for _ in range(max(warmup, 1)):
         links.count_pairs(ref, unk)
+        first_info = first_info or links.last_rank_info
     barrier()
     t0 = time.perf_counter()
+    count_ms_sum, reduce_ms, copy_ms = 0.0, 0.0, 0.0
     for _ in range(steps):
         links.count_pairs(ref, unk)
+        count_ms_sum += links.last_stats.count_ms
+        if links.last_rank_info:
+            reduce_ms += links.last_rank_info["allreduce_ms"]
+            copy_ms += links.last_rank_info["copy_back_ms"]
     barrier()
     elapsed = time.perf_counter() - t0
     stats = links.last_stats
+    multi = multi_gpu_record(dist, world, rank, parallel_device(), links, first_info, count_ms_sum, reduce_ms, copy_ms, steps)
     stat_dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     tens = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
     work = torch.tensor([float(stats.candidate_pairs), float(stats.count_ms)], dtype=torch.float64, device=stat_dev)
@@ -260,7 +305,31 @@ def scaling_probe(steps, warmup, barrier, dist, world, rank):
                          "DD count of crosscorrelate (BASELINE config #5)",
                 metric="candidate pairs/s", value=float(cand[0]) * steps / elapsed, unit="pairs/s", n_gpus=world, steps=steps,
                 ms_per_step=elapsed / steps * 1e3, slowest_rank_count_kernel_ms=float(work[1]), setup_s=setup_s,
-                scaling="strong")
+                scaling="strong", multi_gpu=multi)
+
+
+def multi_gpu_record(dist, world, rank, device, links, first_info, count_ms_sum, reduce_ms, copy_ms, steps):
+    """What lets a reader VERIFY a multi-GPU line (gathered from every rank, printed by rank 0 as ``multi_gpu``): the
+    process-group backend, the world size torch.distributed reports, the device every rank counted and reduced on, its
+    share of the job list, its mean count-kernel / all-reduce / copy-back time per timed step, and what the first call paid
+    once for deriving and broadcasting the job partition (``partition_ms``: outside the timed steps of this bench, inside
+    every fresh ``crosscorrelate``)."""
+    import torch
+
+    info = links.last_rank_info or {}
+    mine = dict(rank=rank, device=int(device), device_name=torch.cuda.get_device_name(device), jobs=info.get("jobs"),
+                route=info.get("route"), count_kernel_ms=count_ms_sum / max(steps, 1), allreduce_ms=reduce_ms / max(steps, 1),
+                copy_back_ms=copy_ms / max(steps, 1), partition_ms=(first_info or {}).get("partition_ms"),
+                pid=os.getpid(), local_rank=int(os.environ.get("LOCAL_RANK", "0")))
+    box = [None] * world
+    dist.all_gather_object(box, mine)
+    if rank != 0:
+        return None
+    return dict(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks=box,
+                distinct_devices=len({(r["device"]) for r in box}),
+                note="one process per GPU: every rank counts its share of the linked patch pairs (LPT over the item builder's "
+                     "work estimate), its rows stay in HBM, ONE sum all-reduce of the [jobs, B, E-1] tensor (RCCL when backend "
+                     "= nccl) completes the result on every rank")
 
 
 # ---------------------------------------------------------------------------------------------- main
@@ -337,17 +406,25 @@ def main():
     gc.collect()
     gc.freeze()
     barrier()
+    first_info = None  # the first call of a sharded count derives and broadcasts the job partition (partition_ms): keep its record
     for _ in range(max(args.warmup, 0)):
         step()
+        first_info = first_info or links.last_rank_info
     barrier()
     t0 = time.perf_counter()
     kernel_ms, count_ms_sum, stats = 0.0, 0.0, None
+    reduce_ms, copy_ms = 0.0, 0.0
     for _ in range(args.steps):
         stats = step()
         kernel_ms += stats.kernel_ms          # HIP events on the library's stream: first to last kernel of the call
         count_ms_sum += stats.count_ms        # ... and around the count kernel alone
+        first_info = first_info or links.last_rank_info
+        if links.last_rank_info:
+            reduce_ms += links.last_rank_info["allreduce_ms"]
+            copy_ms += links.last_rank_info["copy_back_ms"]
     barrier()
     elapsed = time.perf_counter() - t0
+    multi = multi_gpu_record(dist, world, rank, device, links, first_info, count_ms_sum, reduce_ms, copy_ms, args.steps) if world > 1 else None
 
     # whole-job numbers: max time over ranks, sum of per-rank work
     stat_dev = "cuda" if (world == 1 or dist.get_backend() == "nccl") else "cpu"
@@ -377,18 +454,21 @@ def main():
         # kernel sources still hash to what that run was made with (build.source_sha16), else null
         from yet_another_wizz_amd.build import source_sha16
 
-        traffic, traffic_source, sq_valu = None, None, None
+        traffic, traffic_source, sq_valu, sq_active_valu = None, None, None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tkey = traffic_key(args, kernel_name, getattr(stats, "band_variant", 0) if stats.kernel_used == 4 else None)
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
-                entry = json.load(f).get(traffic_key(args, kernel_name))
+                entry = json.load(f).get(tkey)
             if isinstance(entry, dict):
                 fresh = entry.get("source_sha16") == source_sha16()
-                traffic_source = {k: entry.get(k) for k in ("source", "commit", "date", "method", "source_sha16")}
+                traffic_source = {k: entry.get(k) for k in ("source", "sq_source", "commit", "date", "method", "source_sha16")}
+                traffic_source["key"] = tkey
                 traffic_source["matches_current_sources"] = fresh
                 if fresh:
                     traffic = entry.get("bytes")
                     sq_valu = entry.get("sq_insts_valu")
+                    sq_active_valu = entry.get("sq_active_inst_valu")
         fp64_equiv = stats.candidate_pairs * 8.0 / k_s / 1e12
         hbm_gbps = stats.algorithmic_bytes / k_s / 1e9
         fp32_tflops = stats.evaluated_pairs * 5.0 / k_s / 1e12
@@ -405,19 +485,32 @@ def main():
             # half the FP64 vector peak. (The kernel decides an entry in float32 wherever float32 can and in float64 inside the
             # guard bands, so this is an FP64-EQUIVALENT rate: it can exceed what FP64 arithmetic could reach.)
             ev_tflops = stats.evaluated_pairs * 8.0 / k_s / 1e12
+            # The arithmetic the float32 band kernel EXECUTES: per evaluated entry 3 subtractions + 3 fused multiply-adds in
+            # packed float32 = 9 flop -> against the FP32 vector peak; and the share of the kernel's time its SIMDs spend
+            # issuing vector instructions at all (SQ_ACTIVE_INST_VALU counts quad-cycles: x 4 cycles, over 1024 SIMDs x clock x time).
+            fp32_exec = stats.evaluated_pairs * 9.0 / k_s / 1e12
+            is32 = getattr(stats, "band_variant", 0) in (32, 33)
+            walk_insts = stats.evaluated_pairs / 128.0 * WALK_VALU_PER_TRIP  # an ideal walk: every trip 64 lanes x 2 evaluations
             roofline = dict(
                 bound="valu_fp64", achieved=ev_tflops, peak=peak_nofma, unit="TFLOP/s", frac=ev_tflops / peak_nofma,
                 traffic=traffic, traffic_source=traffic_source,
                 achieved_hbm_gbps=(traffic / k_s / 1e9 if traffic else None),
                 achieved_hbm_frac=(traffic / k_s / 1e9 / HBM_PEAK_GBPS if traffic else None),
                 evaluated_entries_per_launch=stats.evaluated_pairs,
-                essential_valu_frac=(stats.evaluated_pairs * 10.0 / 64.0 / sq_valu if sq_valu else None),
+                fp32_frac=(fp32_exec / FP32_VECTOR_PEAK_TFLOPS if is32 else None),
+                fp32_achieved_tflops=(fp32_exec if is32 else None), fp32_peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
+                valu_issue_frac=(sq_active_valu * 4.0 / (N_SIMDS * SHADER_CLOCK_HZ * k_s) if sq_active_valu else None),
+                essential_valu_frac=(walk_insts / sq_valu if sq_valu and is32 else None),
                 note="achieved = evaluated band entries x 8 FP64-equivalent flop / count-kernel time, peak = FP64 vector peak "
-                     "without FMA; achieved_hbm_gbps = HBM bytes of the count kernel from the rocprofv3 PMC run named in "
-                     "traffic_source ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes) / count-kernel time -- the "
-                     "figure BASELINE.json's metric names; essential_valu_frac = evaluated entries x 10 lane operations "
-                     "(8 flop + 2 compares) / 64 lanes over the wave-level VALU instructions the SQ counted; all three null "
-                     "when the committed counters were taken with other kernel sources",
+                     "without FMA (an FP64-EQUIVALENT rate: the kernel classifies in packed float32, so this is not the "
+                     "utilisation of a hardware unit). Of the hardware it does use: fp32_frac = entries x 9 float32 flop "
+                     "(3 sub + 3 fma) / time / FP32 vector peak; valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / "
+                     "(1024 SIMDs x 2.4 GHz x count-kernel time): the share of the kernel's time the vector ALUs are issuing; "
+                     "essential_valu_frac = wave-level vector instructions an ideal walk needs (entries / 128 per trip x 14) "
+                     "over the SQ_INSTS_VALU counted. achieved_hbm_gbps = HBM bytes of the count kernel from the rocprofv3 PMC "
+                     "run named in traffic_source ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes) / count-kernel time "
+                     "-- the figure BASELINE.json's metric names. Counter-based fields are null when the committed counters "
+                     "were taken with other kernel sources or another kernel variant (traffic_source.key)",
                 brute_force_equivalent=dict(achieved_tflops=fp64_equiv, peak_tflops=peak_nofma, frac=fp64_equiv / peak_nofma,
                                             note="candidate pairs x 8 FP64 flop / time; > 1 because culled pairs are never evaluated"),
             )
@@ -475,6 +568,8 @@ def main():
             candidate_pairs_per_step=cand, evaluated_pairs_per_step=evaluated,
             kernel_ms_per_step=kernel_ms_step, setup_s=setup_s, upload_s=upload_s, roofline=roofline, cpu_baseline=base,
         )
+        if multi is not None:
+            line["multi_gpu"] = multi
     probe = None
     if world > 1 and not args.no_probe:
         ref.drop_layouts()

@@ -11,17 +11,20 @@ P, B = 16, 30
 ARCMIN = np.pi / 10800
 
 
-def _box_catalog(seed, n, with_z, width=60.0, height=30.0, weights=None):
-    """BASELINE config #2's footprint: a 60 x 30 degree box, 16 patches on a regular 4 x 4 grid."""
+def _box_catalog(seed, n, with_z, width=60.0, height=30.0, weights=None, draw_weights=False):
+    """BASELINE config #2's footprint: a 60 x 30 degree box, 16 patches on a regular 4 x 4 grid --
+    bench.box_sky / bench.box_centers, the recipe tools/time_reference.py --box fed to the reference."""
+    import bench
     import yet_another_wizz_amd as yaw
 
-    rng = np.random.default_rng(seed)
-    ra = rng.uniform(0.0, width, n)
-    dec = np.rad2deg(np.arcsin(rng.uniform(0.0, np.sin(np.deg2rad(height)), n)))
-    ga, gd = np.linspace(width / 8, width * 7 / 8, 4), np.linspace(height / 8, height * 7 / 8, 4)
-    centers = yaw.AngularCoordinates(np.deg2rad(np.array([(a, d) for a in ga for d in gd])))
+    ra, dec, rng = bench.box_sky(seed, n, width, height)
+    centers = yaw.AngularCoordinates(bench.box_centers(width, height, 4))
     z = rng.uniform(0.1, 1.0, n) if with_z else None
-    return yaw.Catalog.from_arrays(ra, dec, redshifts=z, weights=weights, patch_centers=centers), (ra, dec, z)
+    if draw_weights:  # as tools/time_reference.py --weights: drawn after the redshifts
+        weights = rng.uniform(0.5, 1.5, n)
+    # radian in, as the reference's run (deg2rad of the recipe's degrees: the same doubles on both sides)
+    return yaw.Catalog.from_arrays(np.deg2rad(ra), np.deg2rad(dec), redshifts=z, weights=weights, patch_centers=centers,
+                                   degrees=False), (ra, dec, z)
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +44,57 @@ def setup():
     fine, stats = engine.count_fine(lref, lunk, jobs, t, kernel="sweep")
     return dict(config=config, ref=ref, unk=unk, lref=lref, lunk=lunk, t=t, jobs=jobs, fine=fine, stats=stats,
                 ref_cols=ref_cols, unk_cols=unk_cols)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_config2_every_slot_against_the_reference(setup, weighted):
+    """BASELINE config #2 at its size against the reference ITSELF: ``tests/golden/fullsize_slots_config2*.npz`` hold the
+    values ``counts[:, i, j]`` of every linked patch pair and the ``sum_weights`` that the reference's
+    ``PatchLinkage.count_pairs`` produced for these inputs (tools/time_reference.py --n-ref 1e6 --n-unk 1e6 --patches 16
+    --box 60x30 [--weights]; src/yaw/correlation/measurements.py:354-364). The AUTO path through the public entry point:
+    exact (unweighted) / 1e-10 (weighted), nothing outside the linked pairs."""
+    import os
+
+    import yet_another_wizz_amd as yaw
+    from conftest import GOLDEN
+    from yet_another_wizz_amd import _lib
+
+    slots = np.load(os.path.join(GOLDEN, "fullsize_slots_config2" + ("_weighted" if weighted else "") + ".npz"))
+    assert int(slots["n_ref"]) == 1_000_000 and int(slots["patches"]) == P and tuple(slots["box"]) == (60.0, 30.0)
+    if weighted:
+        ref, _ = _box_catalog(101, 1_000_000, True, draw_weights=True)
+        unk, _ = _box_catalog(202, 1_000_000, False, draw_weights=True)
+        ref.build_trees(setup["config"].binning.edges, closed=setup["config"].binning.closed)
+        unk.build_trees(None)
+    else:
+        ref, unk = setup["ref"], setup["unk"]
+    links = yaw.PatchLinkage.from_catalogs(setup["config"], ref, unk)
+    jobs = links.get_patch_pairs(ref, unk)
+    ids, values = slots["DD_ids"], slots["DD_values"]  # [n, 2], [n, 1, B]
+    assert {tuple(j) for j in jobs.tolist()} == {tuple(j) for j in ids.tolist()}  # the reference's linkage
+    (res,) = links.count_pairs(ref, unk)
+    st = links.last_stats
+    assert st.kernel_used == _lib.KERNEL_BAND and st.band_variant == 32  # the default path, not a chosen kernel
+    assert float(slots["candidate_pairs"]) == float(st.candidate_pairs)
+    got = res.counts.counts[:, ids[:, 0], ids[:, 1]].T  # [n, B]
+    if weighted:
+        np.testing.assert_allclose(got, values[:, 0], rtol=1e-10, atol=0)
+        np.testing.assert_allclose(res.sum_weights.sum_weights1, slots["DD_sum_weights1"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(res.sum_weights.sum_weights2, slots["DD_sum_weights2"], rtol=1e-12, atol=0)
+    else:
+        assert np.array_equal(got, values[:, 0])
+        assert np.array_equal(res.sum_weights.sum_weights1, slots["DD_sum_weights1"])
+        assert np.array_equal(res.sum_weights.sum_weights2, slots["DD_sum_weights2"])
+        # and the module's all-pairs job table (unlinked pairs included) on the sweep kernel holds the same numbers
+        full = setup["fine"].reshape(P, P, B)
+        assert np.array_equal(full[ids[:, 0], ids[:, 1]], values[:, 0])
+    assert values.sum() > 4e7
+    mask = np.ones((P, P), dtype=bool)
+    mask[ids[:, 0], ids[:, 1]] = False
+    assert not res.counts.counts[:, mask].any()  # nothing outside the linked pairs
+    if weighted:
+        ref.drop_layouts()
+        unk.drop_layouts()
 
 
 def test_three_code_paths_agree_at_1m(setup):

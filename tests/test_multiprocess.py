@@ -115,3 +115,32 @@ def test_partition_is_balanced_and_complete():
     loads = np.array([cost[p].sum() for p in parts])
     assert loads.max() / loads.mean() < 1.05
     assert partition_jobs([], 4)[0].size == 0
+
+
+@pytest.mark.parametrize("env, expect", [
+    (dict(YAW_AMD_DEVICES="3"), 3),                    # what mpirun / srun launchers set per process
+    (dict(YAW_AMD_DEVICE="2", LOCAL_RANK="5"), 2),     # the explicit override wins
+    (dict(LOCAL_RANK="4"), 4),                         # torch.distributed.run
+    (dict(YAW_AMD_DEVICES="5", LOCAL_RANK="1"), 5),
+])
+def test_counting_context_and_collectives_agree_on_the_device(monkeypatch, env, expect):
+    """One source of truth for a rank's GPU: the device the counting context takes (engine.default_devices) is the one the
+    collectives stage on (parallel.local_device_index), whichever variable a launcher sets."""
+    from yet_another_wizz_amd import engine, parallel
+
+    for key in ("YAW_AMD_DEVICES", "YAW_AMD_DEVICE", "LOCAL_RANK"):
+        monkeypatch.delenv(key, raising=False)
+    for key, value in env.items():
+        monkeypatch.setenv(key, value)
+    assert parallel.local_device_index() == expect
+    assert engine.default_devices() == (expect,)
+
+
+def test_several_ids_in_a_group_fall_back_to_the_host_route(monkeypatch):
+    """YAW_AMD_DEVICES naming several ids: a context of several devices -- inside a process group such a rank must not take
+    the device-resident route (single-device contexts only); ``default_devices`` reports what ``count_pairs`` checks."""
+    from yet_another_wizz_amd import engine
+
+    monkeypatch.setenv("YAW_AMD_DEVICES", "0,1")
+    assert engine.default_devices() == (0, 1)
+    assert engine.default_devices(max_workers=1) == (0,)

@@ -82,7 +82,8 @@ if "count:FETCH_SIZE" in pmc and "count:WRITE_SIZE" in pmc:
 
     commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     table[key] = dict(bytes=traffic, source=f"profiles/{name}_pmc.json", commit=commit or None, source_sha16=sha,
-                      sq_insts_valu=(sq.get("sq1") or {}).get("SQ_INSTS_VALU"), sq_source=f"profiles/{name}_sq_counters.json" if sq else None,
+                      sq_insts_valu=(sq.get("sq1") or {}).get("SQ_INSTS_VALU"),
+                      sq_active_inst_valu=(sq.get("sq1") or {}).get("SQ_ACTIVE_INST_VALU"), sq_source=f"profiles/{name}_sq_counters.json" if sq else None,
                       count_kernel_ns=mean([dict(value=r["ns"]) for r in pmc["count:FETCH_SIZE"]]),
                       date=datetime.date.today().isoformat(),
                       method="(2*FETCH_SIZE + WRITE_SIZE)*1024 per count-kernel launch, rocprofv3 --pmc, one counter per pass")

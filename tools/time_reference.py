@@ -49,6 +49,9 @@ def main():
                     help="write the reference's per-slot values counts[s][:, i, j] of every --slot-every'th linked patch "
                          "pair (and the patch ids) to this .npz: the full-size parity fixtures of tests/golden/")
     ap.add_argument("--slot-every", type=int, default=1)
+    ap.add_argument("--box", default=None, metavar="WxH",
+                    help="BASELINE config #2's footprint: a W x H degree box on the equator with a regular grid of patch "
+                         "centres (bench.box_sky / bench.box_centers; --patches must be a square number) instead of the full sky")
     args = ap.parse_args()
 
     os.environ["YAW_NUM_THREADS"] = str(max(args.workers))
@@ -63,7 +66,13 @@ def main():
     import bench  # input recipe only (fibonacci_centers, uniform_sky): no GPU code is touched
 
     n_ref, n_unk = int(args.n_ref), int(args.n_unk)
-    centers = AngularCoordinates(bench.fibonacci_centers(args.patches))
+    box = tuple(float(v) for v in args.box.split("x")) if args.box else None
+    if box:
+        grid = int(round(args.patches ** 0.5))
+        assert grid * grid == args.patches, "--box needs a square number of patches"
+        centers = AngularCoordinates(bench.box_centers(box[0], box[1], grid))
+    else:
+        centers = AngularCoordinates(bench.fibonacci_centers(args.patches))
     shutil.rmtree(args.cache, ignore_errors=True)
     os.makedirs(args.cache)
 
@@ -71,7 +80,11 @@ def main():
     n_rand = int(args.auto_randoms)
 
     def cached(name, seed, n, with_z):
-        ra, dec, rng = bench.uniform_sky(seed, n)
+        if box:
+            ra, dec, rng = bench.box_sky(seed, n, box[0], box[1])
+            ra, dec = np.deg2rad(ra), np.deg2rad(dec)
+        else:
+            ra, dec, rng = bench.uniform_sky(seed, n)
         cols = dict(ra=ra, dec=dec)
         if with_z:
             cols["z"] = rng.uniform(0.1, 1.0, n)
@@ -134,7 +147,7 @@ def main():
     out = dict(
         what="reference PatchLinkage.count_pairs(reference, unknown), trees pre-built (measurements.py:307-367)",
         workload=(f"{n_ref} data + {n_rand} randoms autocorrelation (DD, DR, RR)" if auto else f"{n_ref} ref x {n_unk} unk")
-                 + f", uniform full sky, {args.zbins} z-bins, {args.patches} patches, "
+                 + (f", uniform {args.box} degree box" if args.box else ", uniform full sky") + f", {args.zbins} z-bins, {args.patches} patches, "
                  + ("1-10 arcmin" if args.scales == 1 else "3 log scales 0.5-15.8 arcmin") + (", weighted" if args.weights else ""),
         n_ref=n_ref, n_unk=n_rand if auto else n_unk, patches=args.patches, z_bins=args.zbins, scales=args.scales,
         weighted=bool(args.weights), auto=auto, linked_patch_pairs=len(jobs),
@@ -151,7 +164,7 @@ def main():
     if args.slots_out:
         np.savez_compressed(args.slots_out, n_ref=n_ref, n_unk=n_rand if auto else n_unk, patches=args.patches,
                             z_bins=args.zbins, scales=args.scales, weighted=bool(args.weights), slot_every=args.slot_every,
-                            candidate_pairs=cand, **slots)
+                            candidate_pairs=cand, box=np.array(box if box else (0.0, 0.0)), **slots)
     shutil.rmtree(args.cache, ignore_errors=True)
 
 

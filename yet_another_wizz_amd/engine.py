@@ -26,7 +26,9 @@ def default_devices(max_workers: int | None = None) -> tuple:
     own device; a single process takes every visible GPU (``YAW_AMD_DEVICES="0,1,2"`` picks them explicitly, an id
     may repeat) -- the counterpart of the reference's worker pool, so ``max_workers`` caps their number
     (src/yaw/utils/parallel.py:145-150). Launchers that start one process per GPU without setting LOCAL_RANK (mpirun,
-    srun) must set ``YAW_AMD_DEVICES`` (or ``YAW_AMD_DEVICE``) per process, or every process takes every GPU."""
+    srun) must set ``YAW_AMD_DEVICE`` (or a one-id ``YAW_AMD_DEVICES``) per process, or every process takes every GPU.
+    Inside a group the collectives run on the counting context's device (``Context.device``); a context of SEVERAL
+    devices inside a group counts through the host route (``PatchLinkage.count_pairs``)."""
     env = os.environ.get("YAW_AMD_DEVICES")
     if env:
         devices = [int(v) for v in env.split(",") if v.strip() != ""]

@@ -198,6 +198,7 @@ class PatchLinkage:
         self._job_tables: dict = {}
         self._scatter: dict = {}
         self._partitions: dict = {}
+        self.last_rank_info: dict | None = None
         self._dense_spec = None
 
     def _angular_setup(self):
@@ -306,26 +307,41 @@ class PatchLinkage:
                                             auto=auto)
             return [NormalisedCounts(c, sum_weights) for c in scale_counts]
         # Several ranks: balance what the device will really evaluate (lane tile x window sizes, from the item builder); the
-        # partition is a plan: rank 0 derives it once per (catalogue pair, group size) and broadcasts it
-        # (rank-independent key: every rank enters the broadcast below, or none does)
-        key = (len(layout1.x), len(layout2.x), layout1.num_bins, layout2.num_bins, len(jobs), auto, size)
-        if True:
-            if key not in self._partitions:
-                parts = None
-                if rank == 0:
-                    try:
-                        work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
-                        parts = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
-                    except Exception as err:  # noqa: BLE001 -- the other ranks wait in the broadcast: tell them
-                        parts = err
-                parts = parallel.broadcast_object(parts)
-                if isinstance(parts, Exception):
-                    raise RuntimeError(f"the job partition could not be derived on rank 0: {parts}") from parts
-                self._partitions[key] = parts
-            mine = self._partitions[key][rank]
+        # partition is a plan: rank 0 derives it once per (catalogue pair, thresholds, group size) and broadcasts it.
+        # The key is rank independent (every rank enters the broadcast below, or none does) and identifies the catalogue pair
+        # by content that every rank shares -- per-patch sizes and the sum of weights, not an object id -- and the thresholds.
+        import hashlib
+        import time as _time
+
+        devices = engine.default_devices(max_workers)  # the devices of the context the counts below run on
+        group_device = devices[0]
+        timings = dict(partition_ms=0.0, allreduce_ms=0.0, copy_back_ms=0.0)
+        digest = hashlib.blake2b(digest_size=16)
+        for part in (layout1.offsets, layout2.offsets, thresholds, jobs):
+            digest.update(np.ascontiguousarray(part).tobytes())
+        key = (digest.hexdigest(), layout1.w is not None, layout2.w is not None, auto, size)
+        if key not in self._partitions:
+            t_part = _time.perf_counter()
+            parts = None
+            if rank == 0:
+                try:
+                    work = engine.job_work(layout1, layout2, jobs, thresholds, sort_axis=self.sort_axis)
+                    parts = parallel.partition_jobs(work.astype(np.float64) + JOB_FIXED_COST, size)
+                except Exception as err:  # noqa: BLE001 -- the other ranks wait in the broadcast: tell them
+                    parts = f"{type(err).__name__}: {err}"  # (as text: an exception object may not pickle)
+            parts = parallel.broadcast_object(parts, device=group_device)
+            if isinstance(parts, str):
+                raise RuntimeError(f"the job partition could not be derived on rank 0: {parts}")
+            if len(self._partitions) > 32:
+                self._partitions.clear()
+            self._partitions[key] = parts
+            timings["partition_ms"] = (_time.perf_counter() - t_part) * 1e3
+        mine = self._partitions[key][rank]
         failure, fine, rows = None, None, None
         n_compact = len(jobs) * num_bins * num_fine + 1
-        on_device = parallel.device_collectives() or FORCE_DEVICE_REDUCE
+        # the device-resident route needs ONE device per rank; a context of several devices inside a group (YAW_AMD_DEVICES
+        # naming several ids) counts with the library's in-process split and reduces through the host
+        on_device = (parallel.device_collectives() or FORCE_DEVICE_REDUCE) and len(devices) == 1
         try:
             if on_device:  # this rank's rows stay in HBM, in their place of the full tensor (zero elsewhere)
                 rows, stats = engine.count_rows_device(layout1, layout2, jobs[mine], thresholds, len(jobs), mine,
@@ -343,14 +359,21 @@ class PatchLinkage:
         # one rank, so ONE sum all-reduce (RCCL over xGMI) yields the complete tensor, exactly; one extra element carries
         # the number of ranks that failed, so that all of them raise instead of one leaving the rest blocked in the collective
         if on_device:
-            compact = parallel.allreduce_device_rows(rows, n_compact, status=1.0 if failure is not None else 0.0)
+            compact = parallel.allreduce_device_rows(rows, n_compact, status=1.0 if failure is not None else 0.0,
+                                                     device=group_device, timings=timings)
         else:
             compact = np.zeros(n_compact, dtype=np.float64)
             if failure is not None:
                 compact[-1] = 1.0
             elif len(mine):
                 compact[:-1].reshape(len(jobs), num_bins, num_fine)[mine] = fine
-            compact = parallel.allreduce_sum(compact)
+            t_red = _time.perf_counter()
+            compact = parallel.allreduce_sum(compact, device=group_device)
+            timings["allreduce_ms"] = (_time.perf_counter() - t_red) * 1e3
+        # what a rank's call consisted of, for bench.py's self-verifying multi-GPU line (rank-local; gathered there)
+        self.last_rank_info = dict(rank=rank, device=group_device, jobs=int(len(mine)), route="device" if on_device else "host",
+                                   count_kernel_ms=float(self.last_stats.count_ms) if failure is None and self.last_stats else None,
+                                   **timings)
         if compact[-1] > 0:
             raise RuntimeError(f"pair counting failed on {int(compact[-1])} of {size} ranks") from failure
         fine_bej = np.moveaxis(compact[:-1].reshape(len(jobs), num_bins, num_fine), 0, -1)

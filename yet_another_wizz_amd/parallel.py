@@ -31,9 +31,16 @@ def world() -> tuple[int, int]:
 
 
 def local_device_index() -> int:
-    """GPU of this process: LOCAL_RANK as set by ``python -m torch.distributed.run``
-    (``YAW_AMD_DEVICE`` overrides it, e.g. to let several ranks share one GPU in a test)."""
-    return int(os.environ.get("YAW_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    """GPU of this process: LOCAL_RANK as set by ``python -m torch.distributed.run``; ``YAW_AMD_DEVICE`` overrides it
+    (e.g. to let several ranks share one GPU in a test), and so does a ``YAW_AMD_DEVICES`` that names ONE id (what
+    mpirun / srun launchers set per process): the counting context (``engine.default_devices``) and the collectives
+    then agree on the device whichever of the two variables a launcher uses."""
+    one = os.environ.get("YAW_AMD_DEVICE")
+    if one is None:
+        ids = [v for v in os.environ.get("YAW_AMD_DEVICES", "").split(",") if v.strip() != ""]
+        if len(ids) == 1:
+            one = ids[0]
+    return int(one if one is not None else os.environ.get("LOCAL_RANK", "0"))
 
 
 def partition_jobs(costs, num_parts: int) -> list:
@@ -51,8 +58,9 @@ def partition_jobs(costs, num_parts: int) -> list:
     return [np.array(sorted(p), dtype=np.int64) for p in parts]
 
 
-def allreduce_sum(array: np.ndarray) -> np.ndarray:
-    """Sum ``array`` (int64 or float64) over all ranks; identity for a single process."""
+def allreduce_sum(array: np.ndarray, device: int | None = None) -> np.ndarray:
+    """Sum ``array`` (int64 or float64) over all ranks; identity for a single process. ``device``: the GPU the RCCL
+    backend stages the array on (default: this process' own, ``local_device_index``)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return array
@@ -60,7 +68,7 @@ def allreduce_sum(array: np.ndarray) -> np.ndarray:
 
     tensor = torch.from_numpy(np.ascontiguousarray(array))
     if dist.get_backend() == "nccl":
-        tensor = tensor.to(torch.device("cuda", local_device_index()))
+        tensor = tensor.to(torch.device("cuda", local_device_index() if device is None else int(device)))
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor.cpu().numpy()
 
@@ -71,30 +79,48 @@ def device_collectives() -> bool:
     return dist is not None and dist.get_backend() == "nccl"
 
 
-def allreduce_device_rows(rows, n: int, status: float = 0.0) -> np.ndarray:
+def allreduce_device_rows(rows, n: int, status: float = 0.0, device: int | None = None, timings: dict | None = None) -> np.ndarray:
     """Sum all-reduce of a float64[n] tensor that already lives on this rank's GPU (``_lib.DeviceRows``: the library's
     result buffer, wrapped by torch without a copy) -- or, for a rank that has nothing to contribute (``rows`` None), of
     zeros. ``status`` is added to the last element (the failure flag of ``PatchLinkage.count_pairs``). One device-to-host
-    copy brings the reduced tensor back."""
+    copy brings the reduced tensor back. The collective runs on the GPU that HOLDS the rows (``rows.device``; ``device``
+    for a rank without rows): one source of truth, the counting context's device -- not a second reading of the
+    environment. ``timings``: receives ``allreduce_ms`` (the collective, waited for) and ``copy_back_ms``."""
+    import time
+
     import torch
 
     dist = _dist()
-    device = torch.device("cuda", local_device_index())
+    index = rows.device if rows is not None else (local_device_index() if device is None else int(device))
+    device = torch.device("cuda", index)
     tensor = torch.zeros(n, dtype=torch.float64, device=device) if rows is None else torch.as_tensor(rows, device=device)
     if status:
         tensor[-1] += status
+    t0 = time.perf_counter()
     if dist is not None and dist.get_backend() == "nccl":
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)  # RCCL, on the device
-        return tensor.cpu().numpy()
+        if timings is not None:
+            torch.cuda.synchronize(device)
+            timings["allreduce_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+        out = tensor.cpu().numpy()
+        if timings is not None:
+            timings["copy_back_ms"] = (time.perf_counter() - t0) * 1e3
+        return out
     host = tensor.cpu()  # rehearsals on another backend (several ranks sharing one GPU under gloo): reduce on the host
+    if timings is not None:
+        timings["copy_back_ms"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
     if dist is not None and dist.get_world_size() > 1:
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    if timings is not None:
+        timings["allreduce_ms"] = (time.perf_counter() - t0) * 1e3
     return host.numpy()
 
 
-def broadcast_object(obj, src: int = 0):
+def broadcast_object(obj, src: int = 0, device: int | None = None):
     """``obj`` of rank ``src`` on every rank (a plan such as the job partition: small, sent once); identity for a
-    single process."""
+    single process. ``device``: the GPU the RCCL backend sends it through (default ``local_device_index``)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return obj
@@ -102,7 +128,7 @@ def broadcast_object(obj, src: int = 0):
     if dist.get_backend() == "nccl":  # the object travels through this rank's GPU: name it (torch's current device may be another)
         import torch
 
-        dist.broadcast_object_list(box, src=src, device=torch.device("cuda", local_device_index()))
+        dist.broadcast_object_list(box, src=src, device=torch.device("cuda", local_device_index() if device is None else int(device)))
     else:
         dist.broadcast_object_list(box, src=src)
     return box[0]
