@@ -14,6 +14,9 @@
  *     contiguous, 8-byte aligned; the library owns all device memory behind opaque handles;
  *   - one context = one GPU (yawhip_ctx_create) or several GPUs of the node (yawhip_ctx_create_multi) = one
  *     process; calls are blocking and must not be issued concurrently on the same context;
+ *   - a context remembers what a count call derives from its inputs on the host (kernel choice, job / threshold tables on the
+ *     device) for the next call with the same catalogue pair, job list, thresholds and options: inputs are compared by
+ *     content, the item builder and the count kernels run every call;
  *   - every function returns 0 on success or a negative yawhip_status; nothing throws;
  *     yawhip_last_error() returns a thread-local, human readable message for the last failure.
  */
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define YAWHIP_ABI_VERSION 4
+#define YAWHIP_ABI_VERSION 5
 
 typedef enum yawhip_status {
     YAWHIP_OK = 0,
@@ -39,13 +42,17 @@ typedef enum yawhip_status {
 
 /* Which device code path counts the pairs. All of them return identical results. */
 typedef enum yawhip_kernel {
-    YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path: BAND on strip layouts whose streamed runs are dense,
-                                 SWEEP otherwise (stats->kernel_used tells) */
+    YAWHIP_KERNEL_AUTO = 0,   /* library picks the fastest exact path: BAND on every strip layout of unit vectors (its float32
+                                 kernels; the float64 band kernel -- band_fp32 = 0, more than four edges off a log grid --
+                                 only where the streamed runs are dense), SWEEP on layouts without strips, EXACT for
+                                 input that is not unit vectors (stats->kernel_used / band_variant tell) */
     YAWHIP_KERNEL_EXACT = 1,  /* plain FP64 brute force over every candidate pair */
     YAWHIP_KERNEL_FILTER = 2, /* FP32 guard-banded pre-filter, FP64 re-evaluation of survivors */
     YAWHIP_KERNEL_SWEEP = 3,  /* FILTER + sorted-axis sweep that skips far-away tile pairs */
-    YAWHIP_KERNEL_BAND = 4    /* sorted-axis windows as SWEEP, then per-object bands inside the window evaluated
-                                 directly in FP64 (no pre-filter) (ABI >= 3) */
+    YAWHIP_KERNEL_BAND = 4    /* sorted-axis windows as SWEEP, then every lane object walks only its own band |du| <= r of the
+                                 window: classified in float32 against guard bands around the edges, the evaluations inside a
+                                 guard band decided by the exact FP64 predicate (band_fp32 = 1, default; results identical),
+                                 or every entry in FP64 (band_fp32 = 0) (ABI >= 3) */
 } yawhip_kernel;
 
 typedef struct yawhip_ctx yawhip_ctx;
@@ -159,8 +166,9 @@ int yawhip_catalog_device_bytes(const yawhip_catalog *cat, int64_t *bytes);
 
 /*
  * Count pairs for a list of jobs (replaces measurements.py:344-364 up to, not including, the
- * scatter into [S,B,P,P] and the rweight / scale recombination of trees.py:358-362, which stay
- * on the host because they are O(jobs * B * E)).
+ * scatter into [S,B,P,P] and the rweight / scale recombination of trees.py:358-362: this entry point
+ * returns the per-job fine values; yawhip_count_pairs_dense below does the epilogue as well -- the
+ * recombination of several fine bins on the device, the scatter on the host).
  *   c1, c2     catalogues on the same context with equal n_patches; c1 == c2 is allowed (DD / RR
  *              of an autocorrelation): every ordered pair a != b is then counted, self pairs have
  *              s == 0 and never fall above an edge, exactly as in the reference
@@ -207,6 +215,27 @@ int yawhip_count_pairs_dense(yawhip_ctx *ctx, const yawhip_catalog *c1, const ya
                              const int32_t *jobs, int32_t n_bins, int32_t n_edges, const double *t, int32_t kernel,
                              int32_t n_scales, const int32_t *slices, const double *fine_factors, int32_t halve_diagonal,
                              double *dense, yawhip_stats *stats);
+
+/*
+ * Several counts of ONE measurement from one call (ABI >= 5): the reference's crosscorrelate issues DD, DR, RD, RR back to
+ * back on one linkage (src/yaw/correlation/measurements.py:617-628), autocorrelate DD, DR, RR (:517-523) -- same binning,
+ * thresholds and recombination, other catalogue pairs and job lists. All requests are put on the context's stream at once
+ * (up to four in flight, each with its own work items and result block): the host prepares count k + 1 and writes the
+ * tensor of count k while the device counts. Results are those of n_requests calls of yawhip_count_pairs_dense, bit for bit.
+ *   requests   n_requests records; `dense` and `stats` of every record are written (stats may be NULL)
+ * A context of several devices counts the requests one after the other (each split over the devices).
+ */
+typedef struct yawhip_dense_request {
+    const yawhip_catalog *c1, *c2; /* catalogue pair of this count (c1 == c2: DD / RR of an autocorrelation)      */
+    int32_t n_jobs;                /* linked patch pairs of this count                                            */
+    int32_t halve_diagonal;        /* non-zero: jobs with equal patch ids count x 0.5 (autocorrelation)           */
+    const int32_t *jobs;           /* int32[n_jobs][2]                                                            */
+    double *dense;                 /* out: float64[S][B][P][P]                                                    */
+    yawhip_stats *stats;           /* out, may be NULL                                                            */
+} yawhip_dense_request;
+int yawhip_count_pairs_dense_batch(yawhip_ctx *ctx, int32_t n_requests, const yawhip_dense_request *requests, int32_t n_bins,
+                                   int32_t n_edges, const double *t, int32_t kernel, int32_t n_scales, const int32_t *slices,
+                                   const double *fine_factors);
 
 /*
  * The count of ONE rank of a job list sharded over processes (one process per GPU; ABI >= 4), left on the device for the

@@ -38,12 +38,19 @@ def oracle_count_dense(layout1, layout2, jobs, thresholds, slices, fine_factors,
     return dense, stats
 
 
+def oracle_count_dense_batch(pairs, thresholds, slices, fine_factors, *, kernel=None, sort_axis=2, max_workers=None):
+    """Stand-in for yet_another_wizz_amd.engine.count_dense_batch (``yawhip_count_pairs_dense_batch``): the requests one
+    after the other through the stand-in of the single call."""
+    return [oracle_count_dense(l1, l2, jobs, thresholds, slices, fine_factors, halve) for l1, l2, jobs, halve in pairs]
+
+
 def use_oracle_engine(monkeypatch):
-    """Replace the two seams between the host driver and the HIP library by their oracle stand-ins."""
+    """Replace the seams between the host driver and the HIP library by their oracle stand-ins."""
     from yet_another_wizz_amd import engine
 
     monkeypatch.setattr(engine, "count_fine", oracle_count_fine)
     monkeypatch.setattr(engine, "count_dense", oracle_count_dense)
+    monkeypatch.setattr(engine, "count_dense_batch", oracle_count_dense_batch)
 
 
 def full_catalogs(tag):

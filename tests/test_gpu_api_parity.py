@@ -131,3 +131,100 @@ def test_random_measurements_device_vs_oracle(seed, monkeypatch):
                 total += b.counts.counts.sum()
             np.testing.assert_allclose(cd.sample().data, co.sample().data, rtol=1e-9, atol=1e-12, equal_nan=True)
     assert total > 1000
+
+
+@pytest.mark.parametrize("tag,cfg", [("w", "s2"), ("u", "rw"), ("w", "rw")])
+def test_batch_submission_equals_single_calls_bit_for_bit(tag, cfg):
+    """``yawhip_count_pairs_dense_batch`` (ABI 5; DD, DR, RD, RR of a cross-correlation and DD, DR, RR of an autocorrelation
+    as ONE submission, src/yaw/correlation/measurements.py:617-628,517-523) returns what as many single
+    ``yawhip_count_pairs_dense`` calls return -- every tensor bit for bit, weighted sums included -- with one fine bin per
+    scale (values scattered from the slot's result block) and with separation weights (recombined on the device)."""
+    import yet_another_wizz_amd as yaw
+
+    inp, cats = helpers.full_catalogs(tag)
+    config = helpers.full_config(inp, cfg, "right")
+    ref, unk, rr, ur = cats["ref"], cats["unk"], cats["ref_rand"], cats["unk_rand"]
+    for cat in (ref, rr):
+        cat.build_trees(config.binning.edges, closed=config.binning.closed)
+    for cat in (unk, ur):
+        cat.build_trees(None)
+    links = yaw.PatchLinkage.from_catalogs(config, ref, unk, rr, ur)
+    requests = [((ref, unk), "DD"), ((ref, ur), "DR"), ((rr, unk), "RD"), ((rr, ur), "RR"), ((ref,), "DD"), ((rr,), "RR"),
+                ((None, unk), "RD")]
+    singles = [links.count_pairs(*cats_) if None not in cats_ else None for cats_, _ in requests]
+    for _ in range(2):  # the second round runs on remembered plans
+        batch = links.count_pairs_batch(requests)
+        assert len(batch) == len(requests)
+        for one, many in zip(singles, batch):
+            if one is None:
+                assert many == [None] * config.scales.num_scales
+                continue
+            for a, b in zip(one, many):
+                assert np.array_equal(a.counts.counts, b.counts.counts)
+                assert a.counts.counts.sum() > 0 and a.counts.auto == b.counts.auto
+                assert np.array_equal(a.sum_weights.sum_weights1, b.sum_weights.sum_weights1)
+    # more requests than slots in flight (four): the fifth waits for the first one's slot
+    many = links.count_pairs_batch([((ref, unk), "DD")] * 6)
+    for res in many:
+        assert np.array_equal(res[0].counts.counts, singles[0][0].counts.counts)
+
+
+def test_remembered_plans_follow_their_inputs():
+    """The host side of a call (kernel choice, job and threshold tables on the device) is remembered per set of inputs:
+    same inputs -> same result from the remembered plan; other thresholds, another job list, a changed option or a
+    re-uploaded catalogue -> a fresh plan, never a stale one."""
+    from yet_another_wizz_amd import _lib, engine
+
+    rng = np.random.default_rng(77)
+    P = 6
+
+    def layout(n, bins):
+        import yet_another_wizz_amd as yaw
+
+        ra, dec = rng.uniform(40.0, 48.0, n), rng.uniform(-4.0, 4.0, n)
+        centers = yaw.AngularCoordinates(np.deg2rad([[41.5 + 2.5 * (i % 3), -2.0 + 4.0 * (i // 3)] for i in range(P)]))
+        z = rng.uniform(0.1, 0.9, n) if bins else None
+        cat = yaw.Catalog.from_arrays(ra, dec, redshifts=z, patch_centers=centers)
+        return cat.build_trees(np.linspace(0.1, 0.9, 5) if bins else None)
+
+    l1, l2 = layout(30000, True), layout(40000, False)
+    jobs = np.array([(p, q) for p in range(P) for q in range(P)], dtype=np.int32)
+    t1 = np.tile(np.array([[1e-7, 4e-6]]), (4, 1))
+    t2 = np.tile(np.array([[2e-7, 9e-6]]), (4, 1))
+    truth = {}
+    for name, t, jb in (("t1", t1, jobs), ("t2", t2, jobs), ("half", t1, jobs[::2].copy())):
+        truth[name], _ = engine.count_fine(l1, l2, jb, t, kernel="exact")
+    for _ in range(3):  # alternating inputs: each finds its own plan
+        for name, t, jb in (("t1", t1, jobs), ("t2", t2, jobs), ("half", t1, jobs[::2].copy())):
+            got, st = engine.count_fine(l1, l2, jb, t)
+            assert np.array_equal(got, truth[name]), name
+            assert st.kernel_used == _lib.KERNEL_BAND
+    # thresholds changed IN PLACE behind the same address: compared by content, not by pointer
+    t3 = t1.copy()
+    a, _ = engine.count_fine(l1, l2, jobs, t3)
+    t3[:, 1] = t2[:, 1]
+    t3[:, 0] = t2[:, 0]
+    b, _ = engine.count_fine(l1, l2, jobs, t3)
+    assert np.array_equal(a, truth["t1"]) and np.array_equal(b, truth["t2"])
+    # an option changes the decisions: plans made before it are not used
+    ctx = engine.get_context()
+    ctx.set_option("band_fp32", 0)
+    c, st = engine.count_fine(l1, l2, jobs, t1)
+    ctx.set_option("band_fp32", 1)
+    assert st.band_variant == 64 and np.array_equal(c, truth["t1"])
+    d, st = engine.count_fine(l1, l2, jobs, t1)
+    assert st.band_variant == 32 and np.array_equal(d, truth["t1"])
+    # a catalogue that is freed and uploaded again (possibly at the same address) gets new plans
+    for _ in range(3):
+        for lay in (l1, l2):
+            for dev in list(lay.device.values()):
+                dev.free()
+            lay.device.clear()
+        e, _ = engine.count_fine(l1, l2, jobs, t2)
+        assert np.array_equal(e, truth["t2"])
+    # more distinct inputs than plans kept (16): the oldest go, results stay right
+    for i in range(20):
+        ti = t1 * (1.0 + 0.01 * i)
+        f, _ = engine.count_fine(l1, l2, jobs[: 6 + i], ti)
+        g, _ = engine.count_fine(l1, l2, jobs[: 6 + i], ti, kernel="exact")
+        assert np.array_equal(f, g), i

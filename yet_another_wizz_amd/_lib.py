@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "yawhip_catalog_device_bytes",
     "yawhip_count_pairs",
     "yawhip_count_pairs_dense",
+    "yawhip_count_pairs_dense_batch",
     "yawhip_count_pairs_rows_device",
     "yawhip_job_work",
     "yawhip_assign_patches",
@@ -65,6 +66,19 @@ class _Stats(ctypes.Structure):
         ("exact_reevaluations", ctypes.c_int64),
         ("band_variant", ctypes.c_int32),
         ("merged_triples", ctypes.c_int32),
+    ]
+
+
+class _DenseRequest(ctypes.Structure):
+    """``yawhip_dense_request`` of include/yawhip.h (pointers as plain addresses)."""
+    _fields_ = [
+        ("c1", ctypes.c_void_p),
+        ("c2", ctypes.c_void_p),
+        ("n_jobs", ctypes.c_int32),
+        ("halve_diagonal", ctypes.c_int32),
+        ("jobs", ctypes.c_void_p),
+        ("dense", ctypes.c_void_p),
+        ("stats", ctypes.c_void_p),
     ]
 
 
@@ -133,6 +147,10 @@ def load_library() -> ctypes.CDLL:
     lib.yawhip_count_pairs_dense.argtypes = [  # array arguments as plain addresses (_addr): this is the per-call hot path
         _vp, _vp, _vp, ctypes.c_int32, _vp, ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32,
         ctypes.c_int32, _vp, _vp, ctypes.c_int32, _vp, ctypes.POINTER(_Stats),
+    ]
+    lib.yawhip_count_pairs_dense_batch.argtypes = [
+        _vp, ctypes.c_int32, ctypes.POINTER(_DenseRequest), ctypes.c_int32, ctypes.c_int32, _vp, ctypes.c_int32, ctypes.c_int32,
+        _vp, _vp,
     ]
     lib.yawhip_count_pairs_rows_device.argtypes = [
         _vp, _vp, _vp, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, _dp, ctypes.c_int32,
@@ -318,6 +336,35 @@ def count_pairs_dense(ctx: Context, c1: DeviceCatalog, c2: DeviceCatalog, jobs, 
         "yawhip_count_pairs_dense",
     )
     return dense, CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})
+
+
+def count_pairs_dense_batch(ctx: Context, requests, thresholds, slices, fine_factors, *, kernel="auto"):
+    """Run ``yawhip_count_pairs_dense_batch``: several counts of one measurement (same thresholds and recombination) on the
+    stream at once. ``requests``: sequence of ``(c1, c2, jobs int32[n, 2], halve_diagonal)``. Returns a list of
+    ``(dense f64[S, B, P, P], CountStats)`` in the order of the requests."""
+    n_bins, n_edges = thresholds.shape
+    n_scales = slices.shape[1]
+    reqs = (_DenseRequest * len(requests))()
+    outs, stats, keep = [], [], []
+    for i, (c1, c2, jobs, halve) in enumerate(requests):
+        jobs = np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2)
+        dense = np.empty((n_scales, n_bins, c1.n_patches, c1.n_patches), dtype=np.float64)  # the library writes every element
+        st = _Stats()
+        keep.append(jobs)
+        outs.append(dense)
+        stats.append(st)
+        reqs[i].c1, reqs[i].c2 = c1._h, c2._h
+        reqs[i].n_jobs, reqs[i].halve_diagonal = len(jobs), 1 if halve else 0
+        reqs[i].jobs, reqs[i].dense = jobs.ctypes.data, dense.ctypes.data
+        reqs[i].stats = ctypes.addressof(st)
+    kid = KERNEL_IDS[kernel] if isinstance(kernel, str) else int(kernel)
+    _check(
+        load_library().yawhip_count_pairs_dense_batch(
+            ctx._h, len(requests), reqs, n_bins, n_edges, _addr(thresholds, np.float64), kid, n_scales,
+            _addr(slices, np.int32), _addr(fine_factors, np.float64)),
+        "yawhip_count_pairs_dense_batch",
+    )
+    return [(d, CountStats(**{f: getattr(st, f) for f, _ in _Stats._fields_})) for d, st in zip(outs, stats)]
 
 
 class DeviceRows:

@@ -14,7 +14,7 @@ import os
 from . import _lib
 from .parallel import local_device_index, world
 
-__all__ = ["get_context", "device_catalog", "count_fine", "count_dense", "job_work", "assign_patches", "release", "default_kernel"]
+__all__ = ["get_context", "device_catalog", "count_fine", "count_dense", "count_dense_batch", "job_work", "assign_patches", "release", "default_kernel"]
 
 _contexts: dict = {}
 default_kernel = "auto"
@@ -124,6 +124,27 @@ def count_dense(layout1, layout2, jobs, thresholds, slices, fine_factors, halve_
     return _lib.count_pairs_dense(ctx, d1, d2, np.ascontiguousarray(jobs, dtype=np.int32).reshape(-1, 2),
                                   np.ascontiguousarray(thresholds, dtype=np.float64), slices, fine_factors, halve_diagonal,
                                   kernel=kernel or default_kernel)
+
+
+def count_dense_batch(pairs, thresholds, slices, fine_factors, *, kernel: str | None = None, sort_axis: int = 2,
+                      max_workers: int | None = None):
+    """Several counts of one measurement from ONE library call (``yawhip_count_pairs_dense_batch``): ``pairs`` is a
+    sequence of ``(layout1, layout2, jobs, halve_diagonal)``; all catalogues are uploaded (once) first, then every count is
+    put on the stream. Returns ``[(f64[S, B, P, P], CountStats), ...]`` in the order of ``pairs``."""
+    requests, ctx = [], None
+    for _ in range(3):  # an upload may replace a copy made for another strip grid -- one an earlier pair refers to: look again
+        requests = []
+        for layout1, layout2, jobs, halve in pairs:
+            ctx, d1, d2 = _device_pair(layout1, layout2, thresholds, sort_axis, max_workers)
+            requests.append((d1, d2, jobs, halve))
+        if all(d1._h and d2._h for d1, d2, _, _ in requests):
+            break
+    else:
+        raise _lib.YawhipError("count_dense_batch: the catalogues of the batch do not settle on one strip grid")
+    if not requests:
+        return []
+    return _lib.count_pairs_dense_batch(ctx, requests, np.ascontiguousarray(thresholds, dtype=np.float64), slices, fine_factors,
+                                        kernel=kernel or default_kernel)
 
 
 def count_rows_device(layout1, layout2, jobs, thresholds, n_rows_total: int, row_index, *, kernel: str | None = None,

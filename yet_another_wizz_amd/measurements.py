@@ -398,6 +398,54 @@ class PatchLinkage:
             self._report(count_type_info, len(jobs), self.last_stats, progress)
         return [NormalisedCounts(counts, sum_weights) for counts in scale_counts]
 
+    def count_pairs_batch(self, requests, *, progress: bool = False, max_workers: int | None = None) -> list:
+        """The pair counts of ONE measurement -- ``requests`` = ``[(catalogs, info), ...]`` with ``catalogs`` a tuple of one
+        (auto count) or two catalogues, e.g. DD, DR, RD, RR of ``crosscorrelate``
+        (src/yaw/correlation/measurements.py:617-628) -- as one submission: every count is put on the GPU's stream at once
+        (``yawhip_count_pairs_dense_batch``), the host prepares count k + 1 and writes the tensor of count k while the
+        device counts. Returns what ``count_pairs`` returns for each request, in order (``None`` per scale for a request
+        with a missing catalogue, as ``count_pairs_optional``). With several ranks, or when the device-resident reduce is
+        forced, the counts run one after the other through ``count_pairs``."""
+        num_scales = self.config.scales.num_scales
+        rank, size = parallel.world()
+        results: list = [[None] * num_scales for _ in requests]
+        todo = []
+        for i, (catalogs, info) in enumerate(requests):
+            if len(catalogs) not in (1, 2):
+                raise TypeError("a count takes one or two catalogues")
+            if any(cat is None for cat in catalogs):
+                continue  # (count_pairs_optional: a missing random sample)
+            todo.append((i, catalogs[0], catalogs[1] if len(catalogs) == 2 else None, info))
+        if size > 1 or FORCE_DEVICE_REDUCE or len(todo) <= 1:
+            for i, main, other, info in todo:
+                args = (main,) if other is None else (main, other)
+                results[i] = self.count_pairs(*args, progress=progress, max_workers=max_workers, count_type_info=info)
+            return results
+        binning = self.config.binning.binning
+        num_bins = len(binning)
+        plans, thresholds = self._angular_setup()
+        if self._dense_spec is None:
+            self._dense_spec = self._combine.dense_spec(thresholds.shape[1] - 1)
+        slices, factors = self._dense_spec
+        pairs, meta = [], []
+        for i, main, other, info in todo:
+            auto = other is None
+            cat2 = main if auto else other
+            layout1, layout2 = _active_layout(main, num_bins), _active_layout(cat2, num_bins)
+            jobs = self.get_patch_pairs(main, None if auto else cat2)
+            if info is not None:
+                _log_info("counting %s from patch pairs", info)
+            pairs.append((layout1, layout2, jobs, auto))
+            meta.append((i, layout1, layout2, auto, info, len(jobs)))
+        outs = engine.count_dense_batch(pairs, thresholds, slices, factors, sort_axis=self.sort_axis, max_workers=max_workers)
+        for (i, layout1, layout2, auto, info, n_jobs), (counts, stats) in zip(meta, outs):
+            self.last_stats = stats
+            self._report(info, n_jobs, stats, progress)
+            scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(counts.shape[0])]
+            sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins), auto=auto)
+            results[i] = [NormalisedCounts(c, sum_weights) for c in scale_counts]
+        return results
+
     @staticmethod
     def _report(what, n_jobs, stats, progress) -> None:
         """The reference logs every pair count and shows a progress bar over its patch-pair tasks
@@ -452,10 +500,10 @@ def autocorrelate(config, data: Catalog, random: Catalog, *, count_rr: bool = Tr
     random.build_trees(edges, closed=closed)
     _log_info("computing auto-correlation from DD, DR" + (", RR" if count_rr else ""))
     links = PatchLinkage.from_catalogs(config, data, random)
-    kwargs = dict(progress=progress, max_workers=max_workers)
-    DD = links.count_pairs(data, **kwargs, count_type_info="DD")
-    DR = links.count_pairs(data, random, **kwargs, count_type_info="DR")
-    RR = links.count_pairs_optional(random if count_rr else None, **kwargs, count_type_info="RR")
+    # the reference issues DD, DR, RR one after the other (measurements.py:517-523); here they are ONE submission
+    DD, DR, RR = links.count_pairs_batch(
+        [((data,), "DD"), ((data, random), "DR"), ((random if count_rr else None,), "RR")],
+        progress=progress, max_workers=max_workers)
     return [CorrFunc(dd, dr, None, rr) for dd, dr, rr in zip(DD, DR, RR)]
 
 
@@ -482,9 +530,8 @@ def crosscorrelate(config, reference: Catalog, unknown: Catalog, *, ref_rand: Ca
     _log_info("computing cross-correlation from DD" + (", DR" if count_dr else "") + (", RD" if count_rd else "")
               + (", RR" if count_dr and count_rd else ""))
     links = PatchLinkage.from_catalogs(config, reference, unknown, *randoms)
-    kwargs = dict(progress=progress, max_workers=max_workers)
-    DD = links.count_pairs(reference, unknown, **kwargs, count_type_info="DD")
-    DR = links.count_pairs_optional(reference, unk_rand, **kwargs, count_type_info="DR")
-    RD = links.count_pairs_optional(ref_rand, unknown, **kwargs, count_type_info="RD")
-    RR = links.count_pairs_optional(ref_rand, unk_rand, **kwargs, count_type_info="RR")
+    # the reference issues DD, DR, RD, RR one after the other (measurements.py:617-628); here they are ONE submission
+    DD, DR, RD, RR = links.count_pairs_batch(
+        [((reference, unknown), "DD"), ((reference, unk_rand), "DR"), ((ref_rand, unknown), "RD"), ((ref_rand, unk_rand), "RR")],
+        progress=progress, max_workers=max_workers)
     return [CorrFunc(dd, dr, rd, rr) for dd, dr, rd, rr in zip(DD, DR, RD, RR)]
