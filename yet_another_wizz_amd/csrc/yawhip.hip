@@ -183,6 +183,10 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_SHARE
 #define YAW_B32_SHARE 1  // bands of sparse single-window items are shared out over the wave (k_count_band32)
 #endif
+#ifndef YAW_B32_AW_EARLY
+#define YAW_B32_AW_EARLY 1  // weighted: a lane object's own weight is loaded with its coordinates instead of at the flush, the end of the
+                            // item's chain of dependent memory latencies (config #4: DD 0.370 -> 0.349, DR 1.67 -> 1.56, RR 3.20 -> 3.13 ms)
+#endif
 #ifndef YAW_B32_WAVES_W
 #define YAW_B32_WAVES_W 5  // waves per SIMD the weighted one-annulus variants are compiled for (96 VGPRs; the compiler took 97 by itself: 4 waves, 0.57 against 0.51 ms)
 #endif
@@ -2267,8 +2271,10 @@ struct yawhip_ctx : CallBufs {
     int debug_no_hits = 0;   // diagnostics only: pre-filter threshold above 1 -> no pair survives (timing of the fast path)
     int auto_orient = 1;     // every job runs on the strip layouts of the orientation that suits its patches (0: the catalogues' sort axis)
     int64_t slab_budget = 1ll << 30;  // bytes of per-item partial sums (weighted calls) above which a job list is cut in two
-    int band_grid_div = 4;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest;
-                             // 1, 2, 4 and 8 measure the same at the headline)
+    int band_grid_div = 0;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest);
+                             // 0 = auto: 8, and 16 for the per-bin items of binned x binned counts -- short items of which the
+                             // builder keeps a third (round 4, one box: headline 4 / 8 / 16 -> 0.277 / 0.275 / 0.292 ms; config #4
+                             // DR 1.59 / 1.53 / 1.48, RR 3.08 / 3.04 / 3.02; 1 -> DR 2.16)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
     int item_segments = 1;   // strip builder -> float32 band kernels: the item list in eight segments, one per XCD (append_items)
@@ -2967,7 +2973,7 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
         return YAWHIP_OK;
     }
     if (!strcmp(key, "band_grid_div")) {
-        if (value < 1 || value > 64) return fail(YAWHIP_ERR_INVALID, "band_grid_div must be in [1, 64]");
+        if (value < 0 || value > 64) return fail(YAWHIP_ERR_INVALID, "band_grid_div must be 0 (auto) or in [1, 64]");
         ctx->band_grid_div = (int)value;
         return YAWHIP_OK;
     }
@@ -3946,7 +3952,8 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // Grid from the number of POTENTIAL items (known on the host); the kernel reads the number the builder kept
         // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
         // The strip builder keeps about one potential item in five, ordinary items are all kept.
-        int64_t grid = P.strip_items && n_pot > 65536 ? n_pot / std::max(ctx->band_grid_div, 1) : n_pot;
+        const int grid_div = ctx->band_grid_div > 0 ? ctx->band_grid_div : (P.mode == 3 ? 16 : 8);
+        int64_t grid = P.strip_items && n_pot > 65536 ? n_pot / grid_div : n_pot;
         // items per workgroup visit (unweighted): batches of 4 / 8 when the histogram has hundreds of cells to flush
         const int n_cells = P.lean_bins * P.nf;
         // Batches of consecutive items (one flush of the histogram per batch) are a tunable, off by default: consecutive
