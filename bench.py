@@ -57,6 +57,10 @@ def parse_args():
     ap.add_argument("--weights", action="store_true", help="per-object weights w ~ U(0.5, 1.5) on both catalogues")
     ap.add_argument("--kpc", action="store_true", help="physical scales 100-1000 kpc (thresholds differ from bin to bin) instead of 1-10 arcmin")
     ap.add_argument("--rweight", type=float, default=None, help="separation weight r**rweight (Configuration rweight; resolution 50)")
+    ap.add_argument("--auto-randoms", type=float, default=0.0,
+                    help="> 0: BASELINE config #4 -- a step is the three pair counts of an autocorrelation (DD, DR, RR) of --n-ref "
+                         "data objects and this many randoms, both binned in redshift, submitted as yaw.autocorrelate submits them "
+                         "(one batch); --n-unk is ignored; one GPU")
     ap.add_argument("--no-probe", action="store_true", help="with --gpus > 1: skip the scaling probe (BASELINE config #5) beside the headline")
     return ap.parse_args()
 
@@ -175,7 +179,10 @@ def cpu_baseline(links, ref, unk, budget_s):
 
     c1, c2 = as_cat(l1), as_cat(l2)
     sizes1, sizes2 = l1.segment_sizes(), l2.segment_sizes()
-    cost = sizes1[jobs[:, 0]].sum(axis=1).astype(np.float64) * sizes2[jobs[:, 1]].sum(axis=1)
+    if l1.num_bins > 1 and l2.num_bins > 1:  # binned x binned: only same-bin pairs are candidates
+        cost = (sizes1[jobs[:, 0]].astype(np.float64) * sizes2[jobs[:, 1]]).sum(axis=1)
+    else:
+        cost = sizes1[jobs[:, 0]].sum(axis=1).astype(np.float64) * sizes2[jobs[:, 1]].sum(axis=1)
     # calibrate on the first two jobs, then size the sample to the budget
     t0 = time.perf_counter()
     oracle.count_jobs(c1, c2, jobs[:2], t)
@@ -332,9 +339,120 @@ def multi_gpu_record(dist, world, rank, device, links, first_info, count_ms_sum,
                      "= nccl) completes the result on every rank")
 
 
+def main_autocorrelation(args):
+    """BASELINE config #4 (--auto-randoms): one step = DD + DR + RR of an autocorrelation, submitted as ``yaw.autocorrelate``
+    submits them (``PatchLinkage.count_pairs_batch``: one library call, three counts on the stream). One GPU."""
+    import gc
+
+    import torch
+
+    from yet_another_wizz_amd import PatchLinkage, engine
+    from yet_another_wizz_amd.build import source_sha16
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the pair-count path has no CPU fallback")
+    for item in args.set:
+        key, value = item.split("=", 1)
+        engine.get_context().set_option(key, int(value))
+    t_setup = time.perf_counter()
+    config, data, rand = make_auto_catalogs(args.n_ref, args.auto_randoms, weighted=args.weights, patches=args.patches, zbins=args.zbins)
+    data.build_trees(config.binning.edges, closed=config.binning.closed)
+    rand.build_trees(config.binning.edges, closed=config.binning.closed)
+    links = PatchLinkage.from_catalogs(config, data, rand)
+    setup_s = time.perf_counter() - t_setup
+    requests = [((data,), "DD"), ((data, rand), "DR"), ((rand,), "RR")]
+    t_up = time.perf_counter()
+    links.count_pairs_batch(requests)  # uploads, layouts, plans
+    upload_s = time.perf_counter() - t_up
+    gc.collect()
+    gc.freeze()
+    for _ in range(max(args.warmup, 0)):
+        links.count_pairs_batch(requests)
+    torch.cuda.synchronize()
+    per = {k: dict(count_ms=0.0, kernel_ms=0.0) for k in ("DD", "DR", "RR")}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        links.count_pairs_batch(requests)
+        for k, st in links.last_batch_stats.items():
+            per[k]["count_ms"] += st.count_ms
+            per[k]["kernel_ms"] += st.kernel_ms
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    steps = max(args.steps, 1)
+    stats = links.last_batch_stats
+    cand = float(sum(st.candidate_pairs for st in stats.values()))
+    evaluated = float(sum(st.evaluated_pairs for st in stats.values()))
+    peak_nofma = FP64_VECTOR_PEAK_TFLOPS / 2.0
+    counts = {}
+    traffic_table = {}
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        with open(pmc_file) as f:
+            traffic_table = json.load(f)
+    for k, st in stats.items():
+        ms = per[k]["count_ms"] / steps
+        k_s = max(ms, 1e-9) / 1e3
+        tkey = f"autocorr:{k}:{int(args.n_ref)}+{int(args.auto_randoms)}:p{args.patches}:b{args.zbins}:w{int(bool(args.weights))}:v{st.band_variant}"
+        entry = traffic_table.get(tkey) if isinstance(traffic_table.get(tkey), dict) else None
+        fresh = bool(entry) and entry.get("source_sha16") == source_sha16()
+        traffic = entry.get("bytes") if fresh else None
+        sq_active = entry.get("sq_active_inst_valu") if fresh else None
+        counts[k] = dict(
+            candidate_pairs=int(st.candidate_pairs), evaluated_entries=int(st.evaluated_pairs), work_items=int(st.n_workgroups),
+            exact_reevaluations=int(st.exact_reevaluations), count_kernel_ms=ms, all_kernels_ms=per[k]["kernel_ms"] / steps,
+            band_variant=int(st.band_variant), layout_mode=int(st.layout_mode), merged_triples=int(st.merged_triples),
+            fp64_equiv_frac=st.evaluated_pairs * 8.0 / k_s / 1e12 / peak_nofma,
+            traffic=traffic, achieved_hbm_gbps=(traffic / k_s / 1e9 if traffic else None),
+            valu_issue_frac=(sq_active * 4.0 / (N_SIMDS * SHADER_CLOCK_HZ * k_s) if sq_active else None),
+            traffic_key=tkey, traffic_matches_current_sources=fresh if entry else None)
+    dom = max(counts, key=lambda k: counts[k]["count_kernel_ms"])
+    d = counts[dom]
+    ev_tflops = d["evaluated_entries"] * 8.0 / (d["count_kernel_ms"] / 1e3) / 1e12
+    roofline = dict(
+        bound="valu_fp64", kernel=f"k_count_band32_one ({dom} count: the dominant launch of the step)", achieved=ev_tflops, peak=peak_nofma,
+        unit="TFLOP/s", frac=ev_tflops / peak_nofma, launch_ms=d["count_kernel_ms"], traffic=d["traffic"],
+        achieved_hbm_gbps=d["achieved_hbm_gbps"], achieved_hbm_frac=(d["achieved_hbm_gbps"] / HBM_PEAK_GBPS if d["achieved_hbm_gbps"] else None),
+        valu_issue_frac=d["valu_issue_frac"], counts=counts,
+        count_kernels_ms=sum(c["count_kernel_ms"] for c in counts.values()),
+        fixed_cost_ms=elapsed / steps * 1e3 - sum(c["count_kernel_ms"] for c in counts.values()),
+        note="per-bin items of binned x binned counts: a few hundred evaluations per work item -- the time is per-item latency "
+             "under five to six waves per SIMD (SQ passes: profiles/r04_autocorr_10M_100M_*_sq_counters.json), not arithmetic; "
+             "frac = evaluated entries x 8 FP64-equivalent flop / count-kernel time over the FP64 vector peak without FMA")
+    ref_t = None
+    name = "reference_cpu_auto_10M_100M_weighted.json"
+    if (float(args.n_ref), float(args.auto_randoms), args.patches, args.zbins, bool(args.weights)) == (10e6, 100e6, 64, 30, True) \
+            and os.path.exists(os.path.join(ROOT, "profiles", name)):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            dref = json.load(f)
+        best = {}
+        for r in dref["runs"]:
+            best[r["count"]] = min(best.get(r["count"], 1e99), r["seconds"])
+        ref_t = dict(seconds=sum(best.values()), per_count_seconds=best, cores=max(r["workers"] for r in dref["runs"]),
+                     cpu_model=dref["cpu_model"], scipy=dref["scipy"], where=dref["where"], source=f"profiles/{name}", what=dref["what"])
+    base = None
+    if args.cpu_seconds > 0:
+        base = cpu_baseline(links, data, rand, args.cpu_seconds)  # the DR count's first jobs: binned x binned brute force
+        base["reference"] = ref_t
+    line = dict(
+        metric="candidate pairs/s", value=cand * steps / elapsed, unit="pairs/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+        ms_per_step=elapsed / steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"{int(args.n_ref)} data + {int(args.auto_randoms)} randoms uniform full sky, {args.zbins} z-bins, "
+                             f"{args.patches} patches, 1 scale 1-10 arcmin" + (", weighted" if args.weights else "")
+                             + ", DD + DR + RR of autocorrelate (BASELINE config #4)",
+                    n_data=int(args.n_ref), n_random=int(args.auto_randoms), z_bins=args.zbins, patches=args.patches,
+                    parallelism="one GPU, three counts in one submission"),
+        candidate_pairs_per_step=cand, evaluated_pairs_per_step=evaluated, setup_s=setup_s, upload_s=upload_s, roofline=roofline,
+        cpu_baseline=base)
+    print(json.dumps(line), flush=True)
+
+
 # ---------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
+    if args.auto_randoms > 0:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+            raise SystemExit("--auto-randoms runs on one GPU")
+        return main_autocorrelation(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -4242,6 +4242,7 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         }
     }
     const unsigned long long *ctr = reinterpret_cast<const unsigned long long *>(ctx->out.h + cs.o_ctr);
+    g_trace.mark("copied");
     if (stats) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -4272,6 +4273,7 @@ int count_finish(yawhip_ctx *ctx, const CallState &cs, int64_t *fine_counts, dou
         stats->kernel_ms = ms;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cs.wall0).count();
     }
+    g_trace.mark("stats");
     return YAWHIP_OK;
 }
 
@@ -4665,15 +4667,28 @@ int dense_finish(yawhip_ctx *ctx, const yawhip_dense_request &r, int32_t n_bins,
     // converted here (exact below 2^53, the reference's .astype(float64), trees.py:353)
     const int64_t *hc = reinterpret_cast<const int64_t *>(ctx->out.h + ds.cs.o_counts);
     const double *hs = reinterpret_cast<const double *>(ctx->out.h + ds.cs.o_sums);
-    for (int k = 0; k < n_bins; ++k) {  // bin by bin: the scattered writes of one pass stay inside S slices of [P, P]
-        const double w0 = fine_factors ? fine_factors[(size_t)k] : 1.0;
-        for (int s_ = 0; s_ < n_scales; ++s_) {
-            if (!(slices[2 * ((int64_t)k * n_scales + s_) + 1] > slices[2 * ((int64_t)k * n_scales + s_)])) continue;  // (cleared above)
-            double *slice = dense + ((size_t)s_ * n_bins + k) * (size_t)(P * P);
-            for (int64_t j = 0; j < n_jobs; ++j) {
-                const int64_t p = jobs[2 * j], q = jobs[2 * j + 1];
-                const double v = ds.weighted ? hs[(size_t)j * n_bins + (size_t)k] : (double)hc[(size_t)j * n_bins + (size_t)k];
-                slice[p * P + q] = (fine_factors ? v * w0 : v) * ((r.halve_diagonal && p == q) ? 0.5 : 1.0);
+    // position and factor of every job, once; then job by job: a job's B values are read in one piece, each goes to its own
+    // [P, P] slice (13 200 scattered stores at the headline)
+    thread_local std::vector<int64_t> cell;
+    thread_local std::vector<double> half;
+    cell.resize((size_t)n_jobs);
+    half.resize((size_t)n_jobs);
+    for (int64_t j = 0; j < n_jobs; ++j) {
+        cell[(size_t)j] = (int64_t)jobs[2 * j] * P + jobs[2 * j + 1];
+        half[(size_t)j] = (r.halve_diagonal && jobs[2 * j] == jobs[2 * j + 1]) ? 0.5 : 1.0;
+    }
+    const size_t PP = (size_t)(P * P);
+    for (int s_ = 0; s_ < n_scales; ++s_) {
+        double *base = dense + (size_t)s_ * n_bins * PP;
+        for (int64_t j = 0; j < n_jobs; ++j) {
+            double *dst = base + cell[(size_t)j];
+            const double f = half[(size_t)j];
+            const int64_t *cj = hc + (size_t)j * n_bins;
+            const double *sj = hs + (size_t)j * n_bins;
+            for (int k = 0; k < n_bins; ++k) {
+                if (!(slices[2 * ((int64_t)k * n_scales + s_) + 1] > slices[2 * ((int64_t)k * n_scales + s_)])) continue;  // (cleared above)
+                const double v = ds.weighted ? sj[k] : (double)cj[k];
+                dst[(size_t)k * PP] = (fine_factors ? v * fine_factors[(size_t)k] : v) * f;
             }
         }
     }

@@ -199,6 +199,7 @@ class PatchLinkage:
         self._scatter: dict = {}
         self._partitions: dict = {}
         self.last_rank_info: dict | None = None
+        self.last_batch_stats: dict = {}  # count_pairs_batch: CountStats of every count of the last submission, by its name
         self._dense_spec = None
 
     def _angular_setup(self):
@@ -438,8 +439,10 @@ class PatchLinkage:
             pairs.append((layout1, layout2, jobs, auto))
             meta.append((i, layout1, layout2, auto, info, len(jobs)))
         outs = engine.count_dense_batch(pairs, thresholds, slices, factors, sort_axis=self.sort_axis, max_workers=max_workers)
+        self.last_batch_stats = {}
         for (i, layout1, layout2, auto, info, n_jobs), (counts, stats) in zip(meta, outs):
             self.last_stats = stats
+            self.last_batch_stats[info or str(i)] = stats
             self._report(info, n_jobs, stats, progress)
             scale_counts = [PatchedCounts(binning, counts[s], auto=auto) for s in range(counts.shape[0])]
             sum_weights = PatchedSumWeights(binning, layout1.sum_weights_for(num_bins), layout2.sum_weights_for(num_bins), auto=auto)
