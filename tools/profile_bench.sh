@@ -18,4 +18,4 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write
 # 3) SQ counters of the count kernel, two passes of eight
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/sq1" -o run -- python3 "$REPO/bench.py" --cpu-seconds 0 "$@" > /dev/null 2> "$OUT/sq1.err"
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/sq2" -o run -- python3 "$REPO/bench.py" --cpu-seconds 0 "$@" > /dev/null 2> "$OUT/sq2.err"
-find "$OUT" -name "*.csv" | head -40
+find "$OUT" -name "*.csv" | wc -l

@@ -14,8 +14,9 @@ import shutil
 import sys
 
 src, name = sys.argv[1:3]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-labels = sys.argv[4].split(",") if len(sys.argv) > 4 else ["DD", "DR", "RR"]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # 0: the counts CYCLE (DD, DR, RR, DD, ...), as under bench.py --auto-randoms
+labels = sys.argv[4].split(",") if len(sys.argv) > 4 and sys.argv[4] else ["DD", "DR", "RR"]
+traffic_prefix = sys.argv[5] if len(sys.argv) > 5 else None  # e.g. "autocorr:{}:10000000+100000000:p64:b30:w1" -> profiles/pmc_traffic.json
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 sys.path.insert(0, root)
@@ -35,7 +36,10 @@ def groups(sub):
     for r in rows:
         by_dispatch.setdefault(int(r["Dispatch_Id"]), []).append(r)
     for i, did in enumerate(sorted(by_dispatch)):
-        lab = labels[i // reps] if i // reps < len(labels) else f"extra{i // reps}"
+        if reps == 0:
+            lab = labels[i % len(labels)]
+        else:
+            lab = labels[i // reps] if i // reps < len(labels) else f"extra{i // reps}"
         rec = {}
         for r in by_dispatch[did]:
             rec[r["Counter_Name"]] = float(r["Counter_Value"])
@@ -64,6 +68,22 @@ for lab in labels:
                    achieved_hbm_gbps=nbytes / f["ns"], source_sha16=sha,
                    method="(2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, rocprofv3 --pmc, one counter per pass, last of %d launches" % reps)
         json.dump(rec, open(os.path.join(out, f"{name}_{lab}_pmc.json"), "w"), indent=1)
+        if traffic_prefix:
+            import datetime
+            import subprocess
+
+            m = re.search(r"k_count_band32(_fine)?", f["kernel"])
+            variant = 33 if (m and m.group(1)) else (32 if m else 64)
+            tfile = os.path.join(out, "pmc_traffic.json")
+            table = json.load(open(tfile)) if os.path.exists(tfile) else {}
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            s1 = (sq[0].get(lab) or {}) if sq else {}
+            table[traffic_prefix.format(lab) + f":v{variant}"] = dict(
+                bytes=nbytes, source=f"profiles/{name}_{lab}_pmc.json", commit=commit or None, source_sha16=sha,
+                sq_insts_valu=s1.get("SQ_INSTS_VALU"), sq_active_inst_valu=s1.get("SQ_ACTIVE_INST_VALU"),
+                sq_source=f"profiles/{name}_{lab}_sq_counters.json", count_kernel_ns=f["ns"], date=datetime.date.today().isoformat(),
+                method="(2*FETCH_SIZE + WRITE_SIZE)*1024 per count-kernel launch, rocprofv3 --pmc, one counter per pass")
+            json.dump(table, open(tfile, "w"), indent=1)
         print(lab, rec["kernel"], f"{nbytes / 1e9:.3f} GB  {f['ns'] / 1e6:.3f} ms  {nbytes / f['ns']:.0f} GB/s")
     rec = {}
     for i, g in enumerate(sq):
