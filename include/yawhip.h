@@ -127,6 +127,9 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *   "triple_runs"       float32 band kernels: the streamed side is read from MERGED runs of three neighbouring strips (one
  *                       window per work item instead of three) when the strip grid is as wide as the largest separation --
  *                       1 (default): where the merged window still fits one LDS stage, 2: always, 0: never (same results)
+ *   "half_bands"        1 (default): a catalogue counted against ITSELF on merged triple runs with one object per lane takes every
+ *                       unordered pair of a diagonal job once and counts it twice (half the walk of DD / RR of an
+ *                       autocorrelation; an exact doubling, also of weighted sums); 0: both sides walk their full bands
  *   "item_segments"     1 (default): the strip builder keeps its work items in eight segments, one per XCD, each with its
  *                       own append counter; 0: one list, dealt to the XCDs in blocks (same results)
  *   "band_grid_div"     band kernels: workgroups = potential work items / this (1..64; default 0 = auto: 8, 16 for the per-bin

@@ -1014,3 +1014,60 @@ def test_weighted_slab_budget_splits_the_job_list(ctx, kernel):
     assert np.array_equal(counts1, counts0) and np.array_equal(sums1, sums0)
     assert st1.candidate_pairs == st0.candidate_pairs and st1.evaluated_pairs == st0.evaluated_pairs
     assert st1.n_launches > st0.n_launches
+
+
+@pytest.mark.parametrize("weights", ["uu", "ww"])
+@pytest.mark.parametrize("lattice", [False, True])
+def test_self_counts_take_every_pair_once_on_the_diagonal(ctx, weights, lattice):
+    """Half bands (round 4): a catalogue counted against itself on merged triple runs with one object per lane meets every
+    unordered pair of a diagonal job from ONE side -- the lane walks only the entries behind its own place in the triple run of
+    its strip -- and counts it twice. Against the oracle's ordered-pair counts (src/yaw/catalog/trees.py:303-362 with tree ==
+    other), with the option off, and on a LATTICE: thousands of objects share their sort key exactly (the order inside the
+    triples must be one total order of objects: key, run, place in the run), many lie exactly on strip boundaries and every
+    object exists twice (pairs at distance zero belong to no bin)."""
+    from yet_another_wizz_amd import _lib
+
+    rng = np.random.default_rng(4242)
+    P, B = 3, 4
+    n = 60000
+    if lattice:
+        g = int(np.sqrt(n / 2))
+        ra, dec = np.meshgrid(np.deg2rad(50.0 + 5.0 * np.arange(g) / g), np.deg2rad(-2.5 + 5.0 * np.arange(g) / g))
+        ra, dec = np.tile(ra.ravel(), 2), np.tile(dec.ravel(), 2)  # every object twice
+    else:
+        ra = np.deg2rad(rng.uniform(50.0, 55.0, n))
+        dec = np.arcsin(rng.uniform(np.sin(np.deg2rad(-2.5)), np.sin(np.deg2rad(2.5)), n))
+    m = len(ra)
+    patch = np.minimum((np.rad2deg(ra) - 50.0) / 5.0 * P, P - 1).astype(np.int64)
+    z = rng.uniform(0.1, 0.9, m)
+    w = rng.uniform(0.5, 1.5, m) if weights == "ww" else None
+    cat = oracle.sort_catalog(ra, dec, z, w, patch, P, np.linspace(0.1, 0.9, B + 1), "right")
+    jobs = np.array([(p, q) for p in range(P) for q in range(p, P)], dtype=np.int32)  # i <= j, as an autocorrelation lists them
+    lim = oracle.parse_ang_limits(np.array([1.0]) * np.pi / 10800, np.array([9.0]) * np.pi / 10800)
+    t = np.stack([oracle.thresholds_for(oracle.ang_bins_for(lim, None, None))] * B)
+    exp_c, exp_s = oracle.count_jobs(cat, cat, jobs, t)
+    diag = jobs[:, 0] == jobs[:, 1]
+    assert exp_c[diag].sum() > 50000 and np.all(exp_c[diag] % 2 == 0)
+    try:
+        ctx.set_option("seg_strips_min_run", 1)
+        ctx.set_option("strip_width_micro", 3000)
+        ctx.set_option("triple_runs", 2)  # merged triple runs whatever the window estimate says
+        dev = _upload(ctx, cat)
+        seen = {}
+        for half in (1, 0):
+            ctx.set_option("half_bands", half)
+            for tile_r in (1, 2, 0):
+                ctx.set_option("tile_r", tile_r)
+                counts, sums, st = _lib.count_pairs(ctx, dev, dev, jobs, t, kernel="band", want_counts=True, want_sums=True)
+                assert st.band_variant == 32 and st.merged_triples == 1 and st.layout_mode == 3
+                assert np.array_equal(counts, exp_c), (half, tile_r)
+                if weights == "ww":
+                    np.testing.assert_allclose(sums, exp_s, rtol=RTOL_W, atol=0)
+                seen[(half, tile_r)] = st.evaluated_pairs
+        # one object per lane: the diagonal jobs (most of the pairs) walk half their bands
+        assert seen[(1, 1)] < 0.7 * seen[(0, 1)]
+        assert seen[(1, 2)] == seen[(0, 2)]  # two objects per lane: unchanged
+    finally:
+        for key, value in (("seg_strips_min_run", 16), ("strip_width_micro", _lib.DEFAULT_STRIP_MICRO), ("triple_runs", 1),
+                           ("half_bands", 1), ("tile_r", 0)):
+            ctx.set_option(key, value)

@@ -183,6 +183,9 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_SHARE
 #define YAW_B32_SHARE 1  // bands of sparse single-window items are shared out over the wave (k_count_band32)
 #endif
+#ifndef YAW_B32_ITEM_PREFETCH
+#define YAW_B32_ITEM_PREFETCH 0  // the record of a workgroup's next item is fetched while it counts the present one
+#endif
 #ifndef YAW_B32_AW_EARLY
 #define YAW_B32_AW_EARLY 1  // weighted: a lane object's own weight is loaded with its coordinates instead of at the flush, the end of the
                             // item's chain of dependent memory latencies (config #4: DD 0.370 -> 0.349, DR 1.67 -> 1.56, RR 3.20 -> 3.13 ms)
@@ -211,6 +214,7 @@ struct DevTab {
     const struct RunGrid *grid;      // strip layouts: per-run index along the sort axis (item builder)
     gf32p qx, qy, qz;          // strip layouts: float32 images of the columns (k_count_band32)
     gi32p idx;                 // merged triple runs (streamed side): index of an entry in the layout's own order, else null
+    gi32p pos3;                // lane side of a self count on merged triple runs: place of an object in its own strip's triple, else null
     int32_t axis;              // sort axis inside a run / segment
     int32_t pad_;
 };
@@ -284,13 +288,16 @@ __global__ __launch_bounds__(256) void k_run_grid(int64_t n_runs, const int64_t 
 // layout's own order for the exact re-evaluation): one window, one search, one walk whose trip count is the longest of 64
 // bands three times as long -- relatively more even. Every object is a member of three triples: 36 bytes of float32 images
 // per object more (+ 4 for the index, + 24 with weights). c runs over [first strip - 1, last strip + 1] of the group.
-// One thread per entry: its place in each of its three triples is its rank among the members (ties: lower run first).
+// One thread per entry: its place in each of its three triples is its rank among the members (ties: lower run first) -- the
+// order (key, run, position in the run) is the SAME total order of objects in every triple two objects share, which is what
+// lets a self count take every unordered pair once: a lane object walks only the entries BEHIND its own place in the triple
+// of its strip (pos3), and the pair (a, b) is then met from exactly one side (k_count_band32_one, half bands).
 __global__ __launch_bounds__(256) void k_merge_triples(int64_t n, int64_t n_runs, const int64_t *__restrict__ off,
                                                        const int32_t *__restrict__ run_group, const int64_t *__restrict__ vbase,
                                                        const int64_t *__restrict__ off3, const double *__restrict__ key,
                                                        const float *__restrict__ q, int64_t q_stride, const double *__restrict__ w,
                                                        float *__restrict__ q3, int64_t q3_stride, double *__restrict__ w3,
-                                                       int32_t *__restrict__ idx3) {
+                                                       int32_t *__restrict__ idx3, int32_t *__restrict__ pos3) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t lo = 0, hi = n_runs;  // run of the entry: the largest r with off[r] <= i
@@ -327,6 +334,7 @@ __global__ __launch_bounds__(256) void k_merge_triples(int64_t n, int64_t n_runs
         q3[dst] = fx; q3[q3_stride + dst] = fy; q3[2 * q3_stride + dst] = fz;
         idx3[dst] = (int32_t)i;
         if (w3) w3[dst] = wi;
+        if (d == 0) pos3[i] = (int32_t)dst;  // where the object stands in the triple of its OWN strip (half bands of self counts)
     }
 }
 
@@ -496,7 +504,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         }
         const int job = lo;
         const JobRec jr = jobs[job];
-        const int o = jr.o;  // orientation of the job: which pair of layouts it runs on
+        const int o = jr.o & 3;  // orientation of the job: which pair of layouts it runs on
+        it.pad_ = (jr.o >> 2) & 1;  // 1: diagonal job of a self count: lanes walk only the entries behind their own place (see k_merge_triples)
         // swap: the lane tiles come from the first catalogue of the job (the binned one), the windows from the second
 #if defined(YAW_BUILD_TABS_GLOBAL)  // (A/B: the records read from the table in global memory, as before)
         const DevTab &c1 = tabs[swap ? 3 + o : o], &c2 = tabs[swap ? o : 3 + o];
@@ -517,7 +526,8 @@ __global__ __launch_bounds__(BUILD_WG) void k_build_items_strips(const DevTab *_
         const TileRec tr = c2.tile_rec[jr.t_lo + tl];
         const int64_t r2 = tr.run, a0 = tr.a0, a1 = a0 + tr.na;
         const double kpad = triple ? 1.2e-7 : 0.0;  // float32 rounding of a streamed key (|u| <= 1: 2^-24)
-        const double wlo = key2[a0] - rwin - kpad, whi = key2[a1 - 1] + rwin + kpad;
+        // (half bands: no lane of the tile looks at an entry in front of the tile's first object -- the window starts there)
+        const double wlo = key2[a0] - (it.pad_ ? 0.0 : rwin) - kpad, whi = key2[a1 - 1] + rwin + kpad;
         it.a0 = a0; it.na = tr.na; it.nwin = 0;
         it.slot = (int32_t)((unsigned)job | ((unsigned)o << 30)); it.pot = (int32_t)pot;
         // The windows of the (up to) three partner runs are searched in lockstep: three independent chains of loads per
@@ -2159,7 +2169,8 @@ inline DevTab make_tab(const double *x, const double *y, const double *z, const 
                        const int64_t *vbase, const int64_t *slo, const int64_t *tiles, const TileRec *tile_rec, const RunGrid *grid,
                        int axis, const float *q = nullptr, int64_t q_stride = 0, const int32_t *idx = nullptr) {
     return DevTab{(gf64p)x, (gf64p)y, (gf64p)z, (gf64p)w, (gi32p)k, (gi64p)off, (gi64p)vbase, (gi64p)slo, (gi64p)tiles,
-                  tile_rec, grid, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), (gi32p)idx, axis, 0};
+                  tile_rec, grid, (gf32p)q, (gf32p)(q ? q + q_stride : nullptr), (gf32p)(q ? q + 2 * q_stride : nullptr), (gi32p)idx,
+                  (gi32p)nullptr, axis, 0};
 }
 
 template <typename T>
@@ -2278,6 +2289,7 @@ struct yawhip_ctx : CallBufs {
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
     int item_segments = 1;   // strip builder -> float32 band kernels: the item list in eight segments, one per XCD (append_items)
+    int half_bands = 1;      // self counts on merged triple runs, one object per lane: diagonal jobs take every unordered pair once (x 2)
     int triple_runs = 1;     // float32 band kernels stream merged triple runs (k_merge_triples) when the partner strips are c - 1, c, c + 1
     int band_fp32 = 1;       // band kernel on strip layouts of unit vectors: float32 classification + exact float64 for the
                              // guard bands (k_count_band32); 0: every entry in float64 (k_count_band)
@@ -2333,6 +2345,7 @@ struct StripLayout {
     int64_t q3_stride = 0;
     double *w3 = nullptr;             // weights in merged order
     int32_t *idx3 = nullptr;          // [3 n] entry -> index in the layout's own order
+    int32_t *pos3 = nullptr;          // [n] object -> its place in the triple run centred on its own strip
     int64_t *off3 = nullptr;          // [V + 2 G + 1] offsets of the triple runs: group g has its strips + 2, first one = vbase[g] + 2 g
     RunGrid *d_grid3 = nullptr;       // [V + 2 G + 1]
     int64_t n_groups = 0;
@@ -2342,9 +2355,9 @@ struct StripLayout {
     void release() {
         for (void *ptr : {(void *)x, (void *)y, (void *)z, (void *)w, (void *)k, (void *)q, (void *)off, (void *)d_vbase, (void *)d_slo,
                           (void *)d_tiles[0], (void *)d_tiles[1], (void *)d_tiles[2], (void *)d_tile_rec[0], (void *)d_tile_rec[1],
-                          (void *)d_tile_rec[2], (void *)d_grid, (void *)q3, (void *)w3, (void *)idx3, (void *)off3, (void *)d_grid3})
+                          (void *)d_tile_rec[2], (void *)d_grid, (void *)q3, (void *)w3, (void *)idx3, (void *)pos3, (void *)off3, (void *)d_grid3})
             if (ptr) (void)hipFree(ptr);
-        q3 = nullptr; w3 = nullptr; idx3 = nullptr; off3 = nullptr; d_grid3 = nullptr; triples = false;
+        q3 = nullptr; w3 = nullptr; idx3 = nullptr; pos3 = nullptr; off3 = nullptr; d_grid3 = nullptr; triples = false;
         x = y = z = w = nullptr; k = nullptr; q = nullptr; off = d_vbase = d_slo = nullptr;
         d_tiles[0] = d_tiles[1] = d_tiles[2] = nullptr;
         d_tile_rec[0] = d_tile_rec[1] = d_tile_rec[2] = nullptr;
@@ -2804,6 +2817,7 @@ int build_triples(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     int32_t *d_run_group = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&L.q3), (size_t)3 * L.q3_stride * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.idx3), n3 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.pos3), (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t));
     if (e == hipSuccess && c->w) e = hipMalloc(reinterpret_cast<void **>(&L.w3), n3 * sizeof(double) + 16);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.off3), (size_t)(V3 + 1) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&L.d_grid3), (size_t)(V3 + 1) * sizeof(RunGrid));
@@ -2814,7 +2828,7 @@ int build_triples(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipMemcpyAsync(d_run_group, run_group.data(), run_group.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n > 0) {
         hipLaunchKernelGGL(k_merge_triples, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, V, L.off, d_run_group,
-                           L.d_vbase, L.off3, o == 0 ? L.x : (o == 1 ? L.y : L.z), L.q, L.q_stride, L.w, L.q3, L.q3_stride, L.w3, L.idx3);
+                           L.d_vbase, L.off3, o == 0 ? L.x : (o == 1 ? L.y : L.z), L.q, L.q_stride, L.w, L.q3, L.q3_stride, L.w3, L.idx3, L.pos3);
         hipLaunchKernelGGL(k_run_grid<float>, dim3((unsigned)((V3 * (RUN_GRID + 1) + 255) / 256)), dim3(256), 0, ctx->stream, V3, L.off3,
                            L.q3 + (size_t)o * L.q3_stride, L.d_grid3);
         e = hipGetLastError();
@@ -2822,12 +2836,12 @@ int build_triples(yawhip_ctx *ctx, yawhip_catalog *c, int o, bool seg) {
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_run_group) (void)hipFree(d_run_group);
     if (e != hipSuccess) {
-        for (void *ptr : {(void *)L.q3, (void *)L.w3, (void *)L.idx3, (void *)L.off3, (void *)L.d_grid3})
+        for (void *ptr : {(void *)L.q3, (void *)L.w3, (void *)L.idx3, (void *)L.pos3, (void *)L.off3, (void *)L.d_grid3})
             if (ptr) (void)hipFree(ptr);
-        L.q3 = nullptr; L.w3 = nullptr; L.idx3 = nullptr; L.off3 = nullptr; L.d_grid3 = nullptr;
+        L.q3 = nullptr; L.w3 = nullptr; L.idx3 = nullptr; L.pos3 = nullptr; L.off3 = nullptr; L.d_grid3 = nullptr;
         return fail(e == hipErrorOutOfMemory ? YAWHIP_ERR_OOM : YAWHIP_ERR_HIP, "merged triple runs failed: %s", hipGetErrorString(e));
     }
-    const int64_t bytes = 3 * L.q3_stride * (int64_t)sizeof(float) + (int64_t)n3 * (4 + (c->w ? 8 : 0)) + (V3 + 1) * (int64_t)(sizeof(int64_t) + sizeof(RunGrid));
+    const int64_t bytes = 3 * L.q3_stride * (int64_t)sizeof(float) + (int64_t)n3 * (4 + (c->w ? 8 : 0)) + n * 4 + (V3 + 1) * (int64_t)(sizeof(int64_t) + sizeof(RunGrid));
     L.device_bytes += bytes;
     c->device_bytes += bytes;
     L.triples = true;
@@ -2908,6 +2922,10 @@ int yawhip_ctx_set_option(yawhip_ctx *ctx, const char *key, int64_t value) {
     ctx->plan.key = 0;  // options change the work per job
     ++ctx->opt_gen;     // ... and every decision of a plan
     drop_plans(ctx, nullptr);
+    if (!strcmp(key, "half_bands")) {
+        ctx->half_bands = value != 0;
+        return YAWHIP_OK;
+    }
     if (!strcmp(key, "tile_r")) {
         if (value != 0 && value != 1 && value != 2 && value != 4)
             return fail(YAWHIP_ERR_INVALID, "tile_r must be 0 (auto), 1, 2 or 4");
@@ -3581,6 +3599,11 @@ int make_plan(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c
     // per (job, bin) between the segments (p, k) and (q, k) (groups = segments), numbered like the output slots.
     std::vector<int32_t> sjobs;
     const int64_t n_sjobs = mode == 3 ? n_slots : (int64_t)n_jobs;
+    // Half bands: a catalogue counted against ITSELF meets every unordered pair of a diagonal job twice -- a as lane object with b
+    // in its window, b as lane object with a in its. On merged triple runs with one object per lane the lane walks only the
+    // entries BEHIND its own place in the triple of its strip (one total order of objects in all triples, k_merge_triples): every
+    // pair is met once and counts twice (an exact doubling, also of weighted sums). Half the walk of DD / RR of an autocorrelation.
+    const bool half_ok = band32 && triple && R == 1 && c1 == c2 && !swap && ctx->half_bands != 0 && !job_work;
     if (strip_items) {
         const double width = c1->strip_width;
         // |dv| <= rwin_max  ->  grid indices differ by at most floor(rwin_max / width) + 1
@@ -3600,7 +3623,7 @@ int make_plan(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c
             const StripLayout &sl1 = *LS[o], &sl2 = *LL[o];
             const std::vector<int64_t> &tiles = sl2.h_tiles[tile_idx];
             JobRec &jr = job_recs[(size_t)j];
-            jr.o = o;
+            jr.o = o | (half_ok && p == q ? 4 : 0);
             prefix[(size_t)j] = n_items;
             // strips of q whose grid index lies within `reach` of the strips group p occupies
             const int64_t cnt1 = sl1.h_vbase[(size_t)p + 1] - sl1.h_vbase[(size_t)p], lo1 = sl1.h_slo[(size_t)p];
@@ -3689,6 +3712,7 @@ int make_plan(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c
                 DevTab &tb = h_tabs[swap ? 3 + o : o];
                 tb = make_tab(st.x, st.y, st.z, st.w3, nullptr, st.off3, st.d_vbase, st.d_slo, st.d_tiles[tile_idx],
                               st.d_tile_rec[tile_idx], st.d_grid3, o, st.q3, st.q3_stride, st.idx3);
+                if (half_ok) h_tabs[3 + o].pos3 = (gi32p)b.pos3;  // (c1 == c2: the lane side's layout is the streamed one)
             }
         }
     } else {
@@ -3967,7 +3991,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // 32-bit LDS counters: one stage adds at most 64 R x CAP to a cell, so flush at the latest every
         // 2^32 / (64 R CAP) stages (2^17 for two objects per lane and 192-entry stages, 2^15 for four and 288)
         int flush_log2 = ctx->flush_log2;
-        while (flush_log2 > 0 && ((uint64_t)64 * P.R * P.cap << flush_log2) >= (1ull << 32)) --flush_log2;
+        while (flush_log2 > 0 && ((uint64_t)64 * P.R * 2 * P.cap << flush_log2) >= (1ull << 32)) --flush_log2;  // (x 2: half bands count double)
         const unsigned flush_mask = (1u << flush_log2) - 1u;
         const size_t lds_band32 = band32_lds(P.weighted_any, P.cap, P.lean_bins * P.nf, P.merged && !P.uniform_t ? n_bins : 0, n_edges);
         const bool one_chunk = P.triple || !P.strip_items;  // every item has one window
