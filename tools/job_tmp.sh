@@ -1,1 +1,1 @@
-timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+tools/ab.sh wocc "|--weights" "|--weights --set triple_runs=0" "|--weights --set band_cap=320" "|--weights --set triple_runs=0 --set band_cap=512" "|--set triple_runs=0" "|"
