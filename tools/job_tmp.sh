@@ -1,1 +1,3 @@
-tools/ab.sh wocc "|--weights" "|--weights --set triple_runs=0" "|--weights --set band_cap=320" "|--weights --set triple_runs=0 --set band_cap=512" "|--set triple_runs=0" "|"
+tools/ab_auto2.sh w16 "-|" "w16|" "-|" "w16|"
+C5="--n-ref 5e7 --n-unk 5e7 --patches 128 --scales 3 --steps 5 --warmup 2"
+tools/ab.sh c5fix "|$C5" "prehalf|$C5"

@@ -183,6 +183,8 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #ifndef YAW_B32_SHARE
 #define YAW_B32_SHARE 1  // bands of sparse single-window items are shared out over the wave (k_count_band32)
 #endif
+#define YAW_STR_(x) #x
+#define YAW_STR(x) YAW_STR_(x)
 #ifndef YAW_B32_ITEM_PREFETCH
 #define YAW_B32_ITEM_PREFETCH 0  // the record of a workgroup's next item is fetched while it counts the present one
 #endif
@@ -192,6 +194,9 @@ typedef const __attribute__((address_space(1))) int64_t *gi64p;
 #endif
 #ifndef YAW_B32_WAVES_W
 #define YAW_B32_WAVES_W 5  // waves per SIMD the weighted one-annulus variants are compiled for (96 VGPRs; the compiler took 97 by itself: 4 waves, 0.57 against 0.51 ms)
+#endif
+#ifndef YAW_B32_WAVES_W1
+#define YAW_B32_WAVES_W1 5  // ... with one object per lane (DD / RR of an autocorrelation: 82 VGPRs)
 #endif
 #ifndef YAW_B32_WAVES_BIG
 #define YAW_B32_WAVES_BIG 6  // ... the plain count with the big stage: its 6.3 KB of LDS admit 25 workgroups per CU anyway, and at 80 registers
