@@ -2,6 +2,7 @@
 # Round 4, call A on the GPU box: the GPU test log and the bench lines of every supported configuration (one box).
 O=gpurun_out/round_r04; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -q -m gpu > $O/r04_gpu_tests.log 2>&1; tail -3 $O/r04_gpu_tests.log
+timeout -k 10 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/r04_smoke.log 2>&1; tail -1 $O/r04_smoke.log
 bash tools/collect_round.sh r04
 timeout -k 10 400 python bench.py --steps 10 --warmup 3 --n-ref 1e7 --auto-randoms 1e8 --weights > $O/r04_autocorr_10M_100M_weighted_bench.json 2> $O/autocorr.err; python - <<'PY'
 import json
