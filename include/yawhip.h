@@ -133,7 +133,7 @@ int yawhip_ctx_device_count(const yawhip_ctx *ctx, int *n);
  *   "item_segments"     1 (default): the strip builder keeps its work items in eight segments, one per XCD, each with its
  *                       own append counter; 0: one list, dealt to the XCDs in blocks (same results)
  *   "band_grid_div"     band kernels: workgroups = potential work items / this (1..64; default 0 = auto: 8, 16 for the per-bin
- *                       items of binned x binned counts); the kernel loops over the rest
+ *                       items of binned x binned counts, 4 on clustered catalogues); the kernel loops over the rest
  *   "spin_wait"         1 (default): the host waits for a call's results by polling the stream for the first 2 ms, then blocks;
  *                       0: it blocks at once
  *   "flush_stages_log2" band kernel: the 32-bit LDS counters of an item are flushed to the 64-bit result every

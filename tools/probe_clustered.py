@@ -20,6 +20,9 @@ print(f"set-up {time.perf_counter() - t0:.2f} s")
 for key in ("hist_copies_log2", "band_cap", "tile_r"):
     if os.environ.get("YAW_" + key.upper()):
         engine.get_context().set_option(key, int(os.environ["YAW_" + key.upper()]))
+for _opt in os.environ.get("YAW_SET", "").split(","):  # YAW_SET=key=value,key=value: any context option
+    if "=" in _opt:
+        engine.get_context().set_option(_opt.split("=")[0], int(_opt.split("=")[1]))
 for name, cats in (("cross", (ref, unk)), ("auto", (ref,))):
     links = yaw.PatchLinkage.from_catalogs(config, *cats)
     for kernel in os.environ.get("YAW_KERNELS", "auto band sweep").split():

@@ -2288,9 +2288,7 @@ struct yawhip_ctx : CallBufs {
     int auto_orient = 1;     // every job runs on the strip layouts of the orientation that suits its patches (0: the catalogues' sort axis)
     int64_t slab_budget = 1ll << 30;  // bytes of per-item partial sums (weighted calls) above which a job list is cut in two
     int band_grid_div = 0;   // band kernel on strip items: workgroups = potential items / this (the kernel loops over the rest);
-                             // 0 = auto: 8, and 16 for the per-bin items of binned x binned counts -- short items of which the
-                             // builder keeps a third (round 4, one box: headline 4 / 8 / 16 -> 0.277 / 0.275 / 0.292 ms; config #4
-                             // DR 1.59 / 1.53 / 1.48, RR 3.08 / 3.04 / 3.02; 1 -> DR 2.16)
+                             // 0 = auto (make_plan: 8, 16 for per-bin items, 4 on clustered catalogues)
     int flush_log2 = 17;     // band kernel: stages between flushes of the 32-bit LDS counters = 2^flush_log2
     int spin_wait = 1;       // wait for a call's results by polling the stream for the first 2 ms, then block (0: block at once)
     int item_segments = 1;   // strip builder -> float32 band kernels: the item list in eight segments, one per XCD (append_items)
@@ -3286,6 +3284,7 @@ struct HostPlan {
     // decisions
     bool empty = false;   // nothing to count (no output values)
     bool split = false;   // the job list has to be counted in pieces (SPLIT_JOBS)
+    int grid_div = 8;  // band kernels: workgroups = potential items / this
     int R = 0, band_ne = 0, cap = 0, hp_shift = 0, lean_bins = 0, mode = 0, reach = 0, kernel = 0, nf = 0, n_orient = 0;
     bool band = false, band32 = false, band_fine = false, filter = false, lean = false, merged = false, run_unweighted = false,
          run_weighted = false, strip_items = false, swap = false, sweep = false, triple = false, uniform_t = false, weighted = false,
@@ -3766,6 +3765,24 @@ int make_plan(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalog *c
     P.n_chunks = cprefix.empty() ? 0 : cprefix.back();
     P.n_oslots = n_oslots;
     P.n_orient = (L1[0] ? 1 : 0) + (L1[1] ? 1 : 0) + (L1[2] ? 1 : 0);
+    // Workgroups of the band kernels = potential items / grid_div (the kernel loops over the rest). Uniform catalogues, whose
+    // items are alike, run best with few, longer-lived workgroups: / 8, / 16 for the per-bin items of binned x binned counts, of
+    // which the builder keeps a third (headline 4 / 8 / 16 -> 0.277 / 0.275 / 0.292 ms; config #4 DR 1.59 / 1.53 / 1.48, RR 3.08 /
+    // 3.04 / 3.02). On CLUSTERED catalogues items differ a hundredfold and the hardware's dispatch of many short workgroups is the
+    // load balancer: / 4 (clustered survey, 3M x 4M: cross count 40.1 against 43.3 ms with / 8, autocorrelation count 7.1
+    // against 8.2 with / 16). Clustered = the run the typical OBJECT sits in (sum len^2 / sum len) is more than twice the mean run.
+    {
+        double skew = 1.0;
+        for (const StripLayout *const *LX : {L1, L2})
+            for (int o = 0; o < 3; ++o)
+                if (LX[o] && LX[o]->built) {
+                    const yawhip_catalog *cx = LX == L1 ? c1 : c2;
+                    const double runs = (double)std::max<int64_t>(LX[o]->h_vbase[(size_t)LX[o]->n_groups], 1);
+                    skew = std::max(skew, LX[o]->obj_run / std::max((double)cx->n / runs, 1.0));
+                }
+        P.grid_div = ctx->band_grid_div > 0 ? ctx->band_grid_div : (skew > 2.0 ? 4 : (mode == 3 ? 16 : 8));
+        if (g_trace.on) fprintf(stderr, "[yawhip trace] run skew %.2f -> grid / %d\n", skew, P.grid_div);
+    }
     P.R = R;
     P.abytes = abytes;
     P.band = band;
@@ -3981,7 +3998,7 @@ int count_enqueue(yawhip_ctx *ctx, const yawhip_catalog *c1, const yawhip_catalo
         // Grid from the number of POTENTIAL items (known on the host); the kernel reads the number the builder kept
         // from the device counter, workgroups beyond it exit, workgroups loop if more were kept than the grid holds.
         // The strip builder keeps about one potential item in five, ordinary items are all kept.
-        const int grid_div = ctx->band_grid_div > 0 ? ctx->band_grid_div : (P.mode == 3 ? 16 : 8);
+        const int grid_div = P.grid_div;
         int64_t grid = P.strip_items && n_pot > 65536 ? n_pot / grid_div : n_pot;
         // items per workgroup visit (unweighted): batches of 4 / 8 when the histogram has hundreds of cells to flush
         const int n_cells = P.lean_bins * P.nf;
