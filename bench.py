@@ -618,14 +618,14 @@ def main():
                 fp32_frac=(fp32_exec / FP32_VECTOR_PEAK_TFLOPS if is32 else None),
                 fp32_achieved_tflops=(fp32_exec if is32 else None), fp32_peak_tflops=FP32_VECTOR_PEAK_TFLOPS,
                 valu_issue_frac=(sq_active_valu * 4.0 / (N_SIMDS * SHADER_CLOCK_HZ * k_s) if sq_active_valu else None),
-                essential_valu_frac=(walk_insts / sq_valu if sq_valu and is32 else None),
+                essential_valu_frac=(walk_insts / sq_valu if sq_valu and getattr(stats, "band_variant", 0) == 32 and args.scales == 1 else None),
                 note="achieved = evaluated band entries x 8 FP64-equivalent flop / count-kernel time, peak = FP64 vector peak "
                      "without FMA (an FP64-EQUIVALENT rate: the kernel classifies in packed float32, so this is not the "
                      "utilisation of a hardware unit). Of the hardware it does use: fp32_frac = entries x 9 float32 flop "
                      "(3 sub + 3 fma) / time / FP32 vector peak; valu_issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / "
                      "(1024 SIMDs x 2.4 GHz x count-kernel time): the share of the kernel's time the vector ALUs are issuing; "
-                     "essential_valu_frac = wave-level vector instructions an ideal walk needs (entries / 128 per trip x 14) "
-                     "over the SQ_INSTS_VALU counted. achieved_hbm_gbps = HBM bytes of the count kernel from the rocprofv3 PMC "
+                     "essential_valu_frac = wave-level vector instructions an ideal walk needs (entries / 128 per trip x 14: one "
+                     "annulus per bin, else null) over the SQ_INSTS_VALU counted. achieved_hbm_gbps = HBM bytes of the count kernel from the rocprofv3 PMC "
                      "run named in traffic_source ((2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate passes) / count-kernel time "
                      "-- the figure BASELINE.json's metric names. Counter-based fields are null when the committed counters "
                      "were taken with other kernel sources or another kernel variant (traffic_source.key)",
