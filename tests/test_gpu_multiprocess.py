@@ -19,9 +19,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, backend="gloo", device_reduce=False):
+def _worker(rank, world, port, out_dir, backend="gloo", device_reduce=False, launcher="torchrun"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), YAW_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if launcher == "torchrun":  # LOCAL_RANK per process; YAW_AMD_DEVICE lets the ranks share the one GPU of this box
+        os.environ.update(LOCAL_RANK=str(rank), YAW_AMD_DEVICE="0")
+    else:  # mpirun / srun style: no LOCAL_RANK, the launcher names ONE device per process in YAW_AMD_DEVICES
+        os.environ.pop("LOCAL_RANK", None)
+        os.environ.pop("YAW_AMD_DEVICE", None)
+        os.environ["YAW_AMD_DEVICES"] = "0"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -32,6 +38,10 @@ def _worker(rank, world, port, out_dir, backend="gloo", device_reduce=False):
     from yet_another_wizz_amd import measurements
 
     measurements.FORCE_DEVICE_REDUCE = device_reduce
+    if launcher != "torchrun":  # the counting context and the collectives must name the same device (round-3 advice)
+        from yet_another_wizz_amd import engine, parallel
+
+        assert engine.default_devices() == (0,) and parallel.local_device_index() == 0
     if backend == "nccl":
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
@@ -80,6 +90,20 @@ def test_one_rank_rccl_reduce_on_the_device(tmp_path):
 
     mp.start_processes(_worker, args=(1, _free_port(), str(tmp_path), "nccl", True), nprocs=1, join=True, start_method="spawn")
     assert np.load(tmp_path / "ok0.npy").sum() > 0
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_ranks_named_their_device_by_yaw_amd_devices(tmp_path, backend, world):
+    """Launchers that start one process per GPU without LOCAL_RANK (mpirun, srun) set a one-id YAW_AMD_DEVICES per process:
+    the counting context (engine.default_devices) and the collectives (parallel.local_device_index, DeviceRows.device) then use
+    that device -- round 3 counted on GPU k and reduced on cuda:0. The device-resident route, two gloo ranks and a one-rank
+    RCCL group on the one GPU of this box."""
+    import torch.multiprocessing as mp
+
+    mp.start_processes(_worker, args=(world, _free_port(), str(tmp_path), backend, True, "mpirun"), nprocs=world, join=True,
+                       start_method="spawn")
+    results = [np.load(tmp_path / f"ok{r}.npy") for r in range(world)]
+    assert all(np.array_equal(results[0], r) for r in results[1:]) and results[0].sum() > 0
 
 
 def test_multi_device_context_one_call():
