@@ -8,9 +8,9 @@ catalogues already resident in HBM.  The workload is the configuration BASELINE.
 metric on: 10M reference x 10M unknown objects, uniform full sky, 30 linear z-bins, 64 patches,
 one 1-10 arcmin annulus.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 5
 
 Rank 0 prints ONE JSON line. ``value`` = candidate pairs (sum over linked patch pairs and bins of
 N1*N2, what a brute-force count must decide) of the whole job divided by the slowest rank's time.
@@ -40,8 +40,8 @@ WALK_VALU_PER_TRIP = 14                   # k_count_band32, one annulus, two obj
 def parse_args():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n-ref", type=float, default=10e6)
     ap.add_argument("--n-unk", type=float, default=10e6)
     ap.add_argument("--patches", type=int, default=64)
